@@ -1,0 +1,120 @@
+"""Oracle self-consistency for the build-defined codec (the reference has no bitstream):
+payload bits == reference histogram.SCLV product; decode(encode(x)) == clip(x)."""
+import numpy as np
+import pytest
+
+import oracle
+from tests import helpers
+
+OC = oracle.c
+
+
+def _channels(rng, lens, lo=0.03, hi=6.0):
+    out = []
+    for T in lens:
+        rate = float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+        out.append(np.minimum(rng.poisson(rate, size=T), 255).astype(np.uint8))
+    return out
+
+
+def test_canonical_codebook_matches_reference_literal():
+    # test_chosen_system.py:26-27  encoder = ['0','10','11'] for SCLV [1,2,2]
+    code, ln = OC.codebook([1, 2, 2])
+    assert [format(c, "0%db" % l) for c, l in zip(code, ln)] == ["0", "10", "11"]
+    for S, rows in helpers.sclv_tables().items():
+        for r in rows:
+            code, ln = OC.codebook(r)
+            words = [format(c, "0%db" % l) for c, l in zip(code, ln)]
+            assert len(set(words)) == S
+            for a in words:  # prefix-free
+                assert not any(b != a and b.startswith(a) for b in words)
+    with pytest.raises(ValueError):
+        OC.codebook([1, 1, 2])
+    with pytest.raises(ValueError):
+        OC.codebook([2, 1, 2])
+
+
+@pytest.mark.parametrize("S,h,mode,window", [
+    (3, 6, 1, OC.WIN_REF_HALF), (3, 6, 1, OC.WIN_AFTER_CAL), (5, 2, 1, OC.WIN_REF_HALF),
+    (10, 10, 1, OC.WIN_AFTER_CAL), (7, 3, 0, OC.WIN_REF_HALF), (2, 4, 1, OC.WIN_FULL),
+    (10, 5, 0, OC.WIN_REF_HALF_TRUNC), (8, 7, 1, OC.WIN_FULL),
+])
+def test_roundtrip_and_bit_totals(S, h, mode, window):
+    rng = np.random.RandomState(S * 100 + h)
+    lens = [1, 2, 3, 5, 15, 16, 17, 255, 256, 257, 1000, 16383, 16384, 16385, 40000, 70001]
+    chans = _channels(rng, lens)
+    chans[3][:] = 0
+    chans[5][:] = 250
+    sclv = helpers.sclv_tables()[S]
+    p = OC.Params(S, h, mode, window, sclv, seg_chunks=2)
+    data, off, ln = OC.flatten(chans)
+    enc = OC.encode(data, off, ln, p)
+    m = OC.measure(data, off, ln, p)
+    assert np.array_equal(enc["ch_bits"], m["bits"])  # pin (i)
+    assert np.array_equal(enc["peak"], m["peak"]) and np.array_equal(enc["enc"], m["enc"])
+    seg = enc["seg"]
+    maxlen = int(sclv.max())
+    for s in range(len(seg["ch"])):
+        assert enc["seg_words"][s] <= OC.slot_words(int(seg["n"][s]), maxlen)
+    out = OC.decode(enc["payload"], off, ln, p, enc["peak"], enc["enc"], len(data))
+    for c, x in enumerate(chans):  # pin (ii)
+        T = len(x)
+        cc = min(2 ** h, T)
+        e = cc + T // 2
+        if window == OC.WIN_REF_HALF:
+            w0, w1 = (cc, cc) if e > T else (cc, e)
+        elif window == OC.WIN_REF_HALF_TRUNC:
+            w0, w1 = cc, min(e, T)
+        elif window == OC.WIN_AFTER_CAL:
+            w0, w1 = cc, T
+        else:
+            w0, w1 = 0, T
+        o = int(off[c])
+        assert np.array_equal(out[o + w0:o + w1], np.minimum(x[w0:w1], S - 1)), c
+        assert not out[o:o + w0].any() and not out[o + w1:o + T].any()
+    # header lengths of every chunk add up to the channel totals
+    tot = np.zeros(len(chans), np.uint64)
+    for s in range(len(seg["ch"])):
+        w, left = int(seg["off"][s]), int(seg["n"][s])
+        while left > 0:
+            hdr = enc["payload"][w:w + OC.HDR_WORDS].view(np.uint16)
+            B = int(hdr.sum())
+            tot[seg["ch"][s]] += B
+            w += OC.HDR_WORDS + (B + 31) // 32
+            left -= OC.CHUNK
+        assert w - int(seg["off"][s]) == int(enc["seg_words"][s])
+    assert np.array_equal(tot, enc["ch_bits"])
+
+
+def test_synth_is_deterministic_and_poissonish():
+    C, T = 6, 50000
+    lens = np.full(C, T, np.uint64)
+    offs = (np.arange(C) * T).astype(np.uint64)
+    lam = np.array([0.05, 0.3, 0.8, 1.5, 2.5, 4.0])
+    thr = np.zeros((C, 15), np.uint32)
+    from math import exp, factorial
+    for c in range(C):
+        cdf = 0.0
+        for s in range(15):
+            cdf += exp(-lam[c]) * lam[c] ** s / factorial(s)
+            thr[c, s] = int(np.floor(65536 * cdf))
+    a = OC.synth(offs, lens, thr, 7)
+    b = OC.synth(offs, lens, thr, 7, nthreads=4)
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, OC.synth(offs, lens, thr, 8))
+    for c in range(C):
+        x = a[c * T:(c + 1) * T]
+        assert abs(x.mean() - lam[c]) < 0.05 * max(1.0, lam[c])
+
+
+def test_rebin():
+    rng = np.random.RandomState(3)
+    for T in (1, 4, 5, 6, 99, 100, 1001):
+        x = rng.randint(0, 200, size=T).astype(np.uint8)
+        for r in (1, 2, 5, 10, 50):
+            nb = -(-T // r)
+            pad = np.zeros(nb * r, np.int64)
+            pad[:T] = x
+            want = pad.reshape(nb, r).sum(1)
+            assert np.array_equal(OC.rebin_u32(x, r), want)
+            assert np.array_equal(OC.rebin_u8(x, r), np.minimum(want, 255))
