@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MSamples/s for static-Huffman encode+decode of synthetic Poisson MUA.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the rank's resident batch: calibrate + encode every
+channel's window into the chunked bitstream, then decode it back (both whole-batch kernels,
+inputs already in HBM).  N=1 runs BASELINE.json configs[2] (1024 channels x 1e7 bins, the
+HBM-roofline run) at the reference's chosen design point S=3, 2^6-sample calibration
+histogram, 1 encoder (Compressing data/test_chosen_system.py:22-27); N>1 keeps the same
+per-GPU work (weak scaling; configs[3]'s 10 000-channel set is 1250 channels/GPU:
+--channels-per-gpu 1250).  Channels shard across ranks with no data-path collective; the RCCL
+gather that concatenates the packed bitstream is run once after the timed region and
+reported separately under "gather".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+"roofline" (dominant kernel against the 8 TB/s HBM peak) and "cpu_baseline" (the CPU oracle
+timed on a bounded sample on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--channels-per-gpu", type=int, default=1024)
+    ap.add_argument("--bins", type=int, default=10_000_000)
+    ap.add_argument("--S", type=int, default=3)
+    ap.add_argument("--hist-bits", type=int, default=6)
+    ap.add_argument("--mode", type=int, default=1, help="1 approx-sort mapper, 0 no-sort")
+    ap.add_argument("--seg-chunks", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-channels", type=int, default=16)
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="round-trip check after the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(cs_host, ch_off, ch_len, S, h, mode, tab, seg_chunks, n_ch):
+    """The CPU oracle (oracle/mh_oracle.c, kind "port") timed on the first n_ch channels of the
+    same workload: 1 thread, then all host cores.  Checker code used as a reported baseline
+    only -- it is not on the measured GPU path."""
+    import oracle
+    OC = oracle.c
+    off = np.ascontiguousarray(ch_off[:n_ch])
+    ln = np.ascontiguousarray(ch_len[:n_ch])
+    p = OC.Params(S, h, mode, OC.WIN_AFTER_CAL, tab, seg_chunks=seg_chunks)
+    samples = int((ln - np.minimum(ln, 2 ** h)).sum())
+    res = {}
+    for tag, nt in (("1", 1), ("all", os.cpu_count() or 1)):
+        t0 = time.perf_counter()
+        e = OC.encode(cs_host, off, ln, p, nthreads=nt)
+        t1 = time.perf_counter()
+        OC.decode(e["payload"], off, ln, p, e["peak"], e["enc"], len(cs_host), nthreads=nt)
+        t2 = time.perf_counter()
+        res[tag] = dict(threads=nt, enc_s=t1 - t0, dec_s=t2 - t1,
+                        msamples_s=samples / (t2 - t0) / 1e6)
+        if tag == "1" and (t2 - t0) > 25:
+            break
+    # NumPy single process, measure only: how the reference itself executes (one channel)
+    ONP = oracle.np_
+    x = cs_host[int(off[0]):int(off[0]) + int(ln[0])]
+    t0 = time.perf_counter()
+    st = ONP.channel_stats(np.minimum(x, S - 1), S, 2 ** h, bool(mode))
+    t_np = time.perf_counter() - t0
+    res["numpy_measure_msamples_s"] = (st["e"] - st["c"]) / t_np / 1e6
+    return samples, res
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import muahuff
+    from muahuff import codec, sclv, synth
+
+    S, h, C, T = a.S, a.hist_bits, a.channels_per_gpu, a.bins
+    tab = sclv.table(S)
+    cs = synth.generate(C, T, seed=a.seed, first_channel=rank * C)
+    plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, a.mode, muahuff.WIN_AFTER_CAL, tab, seg_chunks=a.seg_chunks)
+    enc = plan.alloc_encoded()
+    out = torch.zeros_like(cs.data)
+    samples = plan.window_samples
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        plan.encode(cs.data, out=enc)
+        if i is not None:
+            ev[i][1].record()
+        plan.decode(enc, out)
+        if i is not None:
+            ev[i][2].record()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    enc_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(a.steps)]))
+    dec_ms = float(np.mean([ev[i][1].elapsed_time(ev[i][2]) for i in range(a.steps)]))
+    bits = int(enc.ch_bits.sum().item())
+    words = int(enc.seg_words.sum().item())
+    b = bits / samples                 # payload bits/sample (== the reference's histogram.SCLV)
+    cb = words * 32 / samples          # container bits/sample (headers + padding included)
+
+    gather = None
+    if dist is not None and not a.no_gather:
+        from muahuff import dist as mdist
+        dense, tot = plan.compact(enc)
+        barrier()
+        g0 = time.perf_counter()
+        pay, offs = mdist.gather_payload(dense.payload, int(tot.item()), dst=0)
+        barrier()
+        g = time.perf_counter() - g0
+        gather = dict(ms=g * 1e3, bytes_total=int(offs[-1]) * 4,
+                      GBps_into_root=(int(offs[-1]) - int(offs[1])) * 4 / g / 1e9)
+
+    ok = None
+    if a.verify:
+        c = 2 ** h
+        vin = cs.data[:C * T].view(C, T)[:, c:]
+        vout = out[:C * T].view(C, T)[:, c:]
+        ok = bool(torch.equal(torch.clamp(vin, max=S - 1), vout))
+
+    if rank == 0:
+        total_samples = samples * world
+        ms_step = dt / a.steps * 1e3
+        value = total_samples * a.steps / dt / 1e6
+        # dominant kernel = the slower of the two ops of a step
+        if enc_ms >= dec_ms:
+            kname, kms, abytes = "k_encode", enc_ms, samples * (1.0 + b / 8.0)
+        else:
+            kname, kms, abytes = "k_decode", dec_ms, samples * (b / 8.0 + 1.0)
+        achieved = abytes / (kms * 1e-3) / 1e9
+        info = muahuff.device_info(local)
+        line = {
+            "metric": "MSamples/s encode+decode (static-Huffman MUA codec)",
+            "value": value, "unit": "MSamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: synthetic Poisson MUA, %d channels x %.0e bins per GPU, "
+                                   "S=%d, 2^%d-sample calibration, K=%d encoder(s), %s mapper, window [c,T)"
+                                   % (C, T, S, h, tab.shape[0], "approx-sort" if a.mode else "no-sort"),
+                       "channels_per_gpu": C, "bins": T, "S": S, "hist_bits": h, "K": int(tab.shape[0]),
+                       "seg_chunks": a.seg_chunks, "parallelism": "channels sharded x%d, no data-path collective" % world},
+            "bits_per_sample": {"payload": b, "container": cb},
+            "kernels_ms": {"encode_op": enc_ms, "decode_op": dec_ms,
+                           "encode_MSamples_s": samples / enc_ms / 1e3, "decode_MSamples_s": samples / dec_ms / 1e3},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_sample": abytes / samples,
+                         "timing": "HIP events on the launch stream around the op (calibrate+memset+kernel)"},
+            "device": info["name"] + " " + info["arch"],
+        }
+        if gather:
+            line["gather"] = gather
+        if ok is not None:
+            line["verified_roundtrip"] = ok
+        if not a.no_cpu_baseline and world == 1:
+            nch = min(a.cpu_sample_channels, C)
+            nbytes = int(cs.ch_off[nch - 1] + cs.ch_len[nch - 1]) + 64
+            host = cs.data[:nbytes].cpu().numpy()
+            smp, res = cpu_baseline(host, cs.ch_off, cs.ch_len, S, h, a.mode, tab, a.seg_chunks, nch)
+            line["cpu_baseline"] = {"value": res["1"]["msamples_s"], "unit": "MSamples/s", "cores": 1,
+                                    "kind": "port",
+                                    "sample": "first %d channels x %d bins of the same workload (%.2e samples), "
+                                              "oracle/mh_oracle.c encode+decode" % (nch, T, smp),
+                                    "all_cores": res.get("all"), "single": res["1"],
+                                    "numpy_measure_msamples_s": res["numpy_measure_msamples_s"],
+                                    "host_cpus": os.cpu_count()}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,21 @@
+"""MI355X-native static-Huffman compression of binned multi-channel MUA spike counts.
+
+A from-scratch gfx950 implementation of the one data-parallel hot path of
+zhengzhang96/Hardware-efficient-MUA-compression (per-channel calibration histogram,
+approximate-sort mapper, static-Huffman encoder selection, bit totals) plus the bit-packer,
+container and decoder the reference only models.  Kernels live in ``csrc/`` behind the C ABI
+of ``include/muahuff.h`` (``libmuahuff.so``); this package is the Python host side.
+There is no CPU fallback: without the built library and a GPU, device operations raise.
+"""
+from . import _lib, sclv  # noqa: F401
+from ._lib import (CHUNK, MODE_APPROX, MODE_NOSORT, WIN_AFTER_CAL, WIN_FULL,  # noqa: F401
+                   WIN_REF_HALF, WIN_REF_HALF_TRUNC, MuaHuffError, device_info)
+
+__version__ = "0.1.0"
+
+
+def __getattr__(name):  # torch-dependent modules load lazily
+    import importlib
+    if name in ("codec", "container", "synth", "functions_1", "drivers", "dist"):
+        return importlib.import_module("." + name, __name__)
+    raise AttributeError(name)

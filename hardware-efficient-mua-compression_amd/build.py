@@ -1,0 +1,37 @@
+"""Build recipe for libmuahuff.so (hand-written gfx950 HIP kernels + C ABI).
+
+hipcc cross-compiles for gfx950 without a GPU present.  The shared object is built in-tree
+(next to this file) so that it travels with the source snapshot to the GPU box.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO = os.path.join(HERE, "libmuahuff.so")
+SOURCES = ["csrc/muahuff.hip"]
+HEADERS = ["csrc/mh_kernels.hpp", "csrc/mh_device.hpp", "../include/muahuff.h"]
+
+
+def stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+    cmd += [os.path.join(HERE, s) for s in SOURCES] + ["-o", SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=HERE)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

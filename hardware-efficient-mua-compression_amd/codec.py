@@ -1,0 +1,152 @@
+"""Host-side handle on the gfx950 data plane: plan once, then launch measure / encode / decode.
+
+All tensors are torch tensors on the plan's GPU; torch is only the allocator and the stream
+provider here -- every kernel is in libmuahuff.so and is launched on torch's current stream.
+"""
+import ctypes as ct
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (MODE_APPROX, MODE_NOSORT, WIN_AFTER_CAL, WIN_FULL,  # noqa: F401
+                   WIN_REF_HALF, WIN_REF_HALF_TRUNC)
+
+
+def _ptr(t):
+    return ct.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.MuaHuffError(_lib.ERR_NO_DEVICE, "no MI355X visible; this package has no CPU fallback")
+
+
+@dataclass
+class Measured:
+    """What the reference computes per validation channel at one (S, h) --
+    get_BR_with_approx_sort.py:164-193 and the numerator of :289."""
+    cutoff: torch.Tensor      # uint64 [C]   (carried as int64)
+    cal_hist: torch.Tensor    # int32  [C,S] calibration histogram, rank order (val_histograms)
+    peak: torch.Tensor        # uint8  [C]
+    enc: torch.Tensor         # uint8  [C]   first argmin over the plan's SCLV rows
+    post_hist: torch.Tensor   # int64  [C,S] window histogram, rank order (val_histograms_post)
+    bits: torch.Tensor        # int64  [C]   SCLV[enc] . post_hist
+    skipped: torch.Tensor     # uint8  [C]
+
+
+@dataclass
+class Encoded:
+    payload: torch.Tensor     # int32 words; segment s at word seg_off[s]
+    seg_words: torch.Tensor   # int64 [n_segments] words used by each segment
+    ch_bits: torch.Tensor     # int64 [C] exact code bits per channel
+    peak: torch.Tensor
+    enc: torch.Tensor
+    skipped: torch.Tensor
+    seg_off: torch.Tensor = None  # int64 [n_segments] device; None = the plan's slots
+    dense: bool = False
+
+
+class Plan:
+    """One design point (S, h, mapper, window rule, K candidate encoders) over one channel
+    layout.  Mirrors mh_plan_* of include/muahuff.h."""
+
+    def __init__(self, ch_off, ch_len, S, h, mode, window, sclv, seg_chunks=8):
+        _need_gpu()
+        self.ch_off = np.ascontiguousarray(ch_off, dtype=np.uint64)
+        self.ch_len = np.ascontiguousarray(ch_len, dtype=np.uint64)
+        self.sclv = np.ascontiguousarray(np.asarray(sclv, dtype=np.uint8).reshape(-1, int(S)))
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        h_ = ct.c_void_p()
+        rc = _lib.lib().mh_plan_create(ct.byref(h_), self.ch_off.ctypes.data, self.ch_len.ctypes.data,
+                                       len(self.ch_len), int(S), int(h), int(mode), int(window),
+                                       self.sclv.ctypes.data, self.sclv.shape[0], int(seg_chunks))
+        if rc == _lib.ERR_EMPTY_CHANNEL:
+            # the reference fails the same way: functions_1.py:45 indexes data_in[0]
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+        _lib.check(rc)
+        self._h = h_
+        info = _lib.PlanInfo()
+        _lib.check(_lib.lib().mh_plan_info(self._h, ct.byref(info)))
+        self.info = info
+        self.C, self.S = int(info.C), int(info.S)
+        self.n_segments = int(info.n_segments)
+        self.payload_cap_words = int(info.payload_cap_words)
+        self.window_samples = int(info.window_samples)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().mh_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def segments(self):
+        """Host copy of the segment directory."""
+        n = self.n_segments
+        d = dict(ch=np.zeros(n, np.uint32), first=np.zeros(n, np.uint64), n=np.zeros(n, np.uint64),
+                 off=np.zeros(n, np.uint64))
+        _lib.check(_lib.lib().mh_plan_segments(self._h, d["ch"].ctypes.data, d["first"].ctypes.data,
+                                               d["n"].ctypes.data, d["off"].ctypes.data))
+        return d
+
+    # ---- device operations ------------------------------------------------------------
+    def _z(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def measure(self, data, out=None):
+        C, S = self.C, self.S
+        m = out or Measured(self._z(C, torch.int64), self._z((C, S), torch.int32), self._z(C, torch.uint8),
+                            self._z(C, torch.uint8), self._z((C, S), torch.int64), self._z(C, torch.int64),
+                            self._z(C, torch.uint8))
+        _lib.check(_lib.lib().mh_measure(self._h, _ptr(data), _ptr(m.cutoff), _ptr(m.cal_hist), _ptr(m.peak),
+                                         _ptr(m.enc), _ptr(m.post_hist), _ptr(m.bits), _ptr(m.skipped),
+                                         _stream()))
+        return m
+
+    def alloc_encoded(self):
+        C = self.C
+        return Encoded(torch.empty(self.payload_cap_words, dtype=torch.int32, device=self.device),
+                       self._z(max(self.n_segments, 1), torch.int64), self._z(C, torch.int64),
+                       self._z(C, torch.uint8), self._z(C, torch.uint8), self._z(C, torch.uint8))
+
+    def encode(self, data, out=None):
+        e = out or self.alloc_encoded()
+        _lib.check(_lib.lib().mh_encode(self._h, _ptr(data), _ptr(e.payload), e.payload.numel(),
+                                        _ptr(e.seg_words), _ptr(e.ch_bits), _ptr(e.peak), _ptr(e.enc),
+                                        _ptr(e.skipped), _stream()))
+        return e
+
+    def decode(self, enc, out):
+        """out: uint8 tensor with the plan's channel layout; window bytes are overwritten."""
+        _lib.check(_lib.lib().mh_decode(self._h, _ptr(enc.payload), _ptr(enc.seg_off), _ptr(enc.peak),
+                                        _ptr(enc.enc), _ptr(out), _stream()))
+        return out
+
+    def compact(self, enc, dense=None):
+        """Pack the used words of all segments back to back (for storage / the RCCL gather)."""
+        if dense is None:
+            total = int(enc.seg_words.sum().item())
+            dense = torch.empty(total + 4, dtype=torch.int32, device=self.device)
+        off = self._z(max(self.n_segments, 1), torch.int64)
+        tot = self._z(1, torch.int64)
+        _lib.check(_lib.lib().mh_compact(self._h, _ptr(enc.payload), _ptr(enc.seg_words), _ptr(dense),
+                                         dense.numel(), _ptr(off), _ptr(tot), _stream()))
+        return Encoded(dense, enc.seg_words, enc.ch_bits, enc.peak, enc.enc, enc.skipped, off, True), tot
+
+
+def bit_rate(bits, n, BP):
+    """BR = 1000/(BP/(bits/n)) in float64 in the reference's operation order
+    (get_BR_with_approx_sort.py:289-292); 0/0 -> nan for skipped channels."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        abps = np.asarray(bits, dtype=np.float64) / np.asarray(n, dtype=np.float64)
+        return np.float64(1000) / (np.float64(BP) / abps)

@@ -1,0 +1,64 @@
+"""Input container: channels of binned MUA counts, channel-major, in one uint8 device buffer.
+
+The reference keeps ``all_binned_data[BP_idx][dataset_idx][channel]`` = 1-D uint8 array
+(Data/get_all_binned_data.py:36-69; consumers get_BR_with_approx_sort.py:60-75).  On the GPU
+the same channels live back to back in HBM, each starting on a 16-byte boundary so that a
+wavefront reads 1 KiB of one channel per load instruction.
+"""
+import numpy as np
+import torch
+
+ALIGN = 16
+
+
+def layout(lengths, align=ALIGN):
+    """(ch_off, ch_len, total_bytes) for channels of the given lengths."""
+    ln = np.asarray(lengths, dtype=np.uint64)
+    pad = (ln + np.uint64(align - 1)) & ~np.uint64(align - 1)
+    off = np.zeros(len(ln), dtype=np.uint64)
+    if len(ln) > 1:
+        off[1:] = np.cumsum(pad)[:-1]
+    total = int(pad.sum()) if len(ln) else 0
+    return off, ln, total
+
+
+class ChannelSet:
+    """A ragged set of uint8 channels resident on one GPU."""
+
+    def __init__(self, data, ch_off, ch_len):
+        self.data = data  # torch.uint8 [total] on the GPU
+        self.ch_off = np.ascontiguousarray(ch_off, dtype=np.uint64)
+        self.ch_len = np.ascontiguousarray(ch_len, dtype=np.uint64)
+
+    @property
+    def C(self):
+        return len(self.ch_len)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @classmethod
+    def from_channels(cls, channels, device="cuda"):
+        """channels: list of 1-D arrays of counts (values above 255 saturate like MATLAB uint8)."""
+        off, ln, total = layout([len(c) for c in channels])
+        host = np.zeros(total + ALIGN, dtype=np.uint8)
+        for c, o in zip(channels, off):
+            a = np.asarray(c)
+            if a.dtype != np.uint8:
+                a = np.clip(a, 0, 255).astype(np.uint8)
+            host[int(o):int(o) + len(a)] = a
+        return cls(torch.from_numpy(host).to(device), off, ln)
+
+    @classmethod
+    def empty(cls, lengths, device="cuda"):
+        off, ln, total = layout(lengths)
+        return cls(torch.zeros(total + ALIGN, dtype=torch.uint8, device=device), off, ln)
+
+    def channel(self, i):
+        o, n = int(self.ch_off[i]), int(self.ch_len[i])
+        return self.data[o:o + n]
+
+    def to_channels(self):
+        host = self.data.cpu().numpy()
+        return [host[int(o):int(o) + int(n)].copy() for o, n in zip(self.ch_off, self.ch_len)]

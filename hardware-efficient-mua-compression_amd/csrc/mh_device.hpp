@@ -1,0 +1,69 @@
+// mh_device.hpp -- shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "muahuff.h"
+
+namespace mh {
+
+// 16-byte vectors that may sit at any byte address: gfx950 global memory handles unaligned
+// dwordx4 accesses in hardware and hipcc emits global_load/store_dwordx4 for them.
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLanes = MH_LANES;
+constexpr int kRows = MH_ROWS;
+constexpr int kChunk = MH_CHUNK;
+constexpr int kHdrWords = MH_HDR_WORDS;
+constexpr int kLut = 16;      // symbol LUT entries: index min(raw value, 15)
+constexpr int kDtab = 512;    // decode table bytes per channel (2^maxlen <= 512)
+constexpr int kHistStride = 16;
+#define MH_LUT_SYMS 10  // S <= 10 (the reference sweeps S = 2..10)
+
+// rank of symbol s for a calibration histogram peaking at p (closed form of the reference's
+// approx_sort, Compressing data/functions_1.py:75-90: order p, p-1, p+1, p-2, p+2, ... with
+// the exhausted side skipped); identity for the no-sort mapper.
+__host__ __device__ inline int rank_of_symbol(int mode, int S, int p, int s)
+{
+    if (mode == MH_MODE_NOSORT) return s;
+    const int d = s - p, ad = d < 0 ? -d : d;
+    const int a = p, b = S - 1 - p, m = a < b ? a : b;
+    if (d == 0) return 0;
+    if (ad <= m) return d < 0 ? 2 * ad - 1 : 2 * ad;
+    return m + ad;
+}
+
+// inverse: symbol that holds rank k
+__host__ __device__ inline int symbol_of_rank(int mode, int S, int p, int k)
+{
+    if (mode == MH_MODE_NOSORT) return k;
+    const int a = p, b = S - 1 - p, m = a < b ? a : b;
+    if (k == 0) return p;
+    if (k <= 2 * m) {
+        const int j = (k + 1) >> 1;
+        return (k & 1) ? p - j : p + j;
+    }
+    const int j = k - m;
+    return a > b ? p - j : p + j;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+}  // namespace mh

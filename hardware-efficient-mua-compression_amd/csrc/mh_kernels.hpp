@@ -1,0 +1,608 @@
+// mh_kernels.hpp -- hand-written gfx950 kernels of the hot path.
+//
+//   k_calibrate      one wave per channel: cutoff, calibration histogram, peak, permutation,
+//                    first-min encoder, per-channel encode LUT
+//   k_hist<NS>       window histogram, byte-parallel compares, 16 B/lane coalesced reads
+//   k_finalize       rank-map the histogram, bits = SCLV[enc] . post
+//   k_encode<FI>     one wave per segment: LUT lookup, per-lane bit accumulation, LDS staging,
+//                    wave prefix sum of sub-stream lengths, LDS merge, coalesced flush
+//   k_build_dtab     per-channel decode tables from (peak, enc)
+//   k_decode<FI>     one wave per segment: one lane per sub-stream, table decode, 16 B stores
+//   k_scan_words / k_compact   dense re-packing of the segment slots
+//   k_synth / k_rebin          synthetic MUA generator, per-channel re-binning
+//
+// All integer / bit work, HBM-bound: no MFMA anywhere.
+#pragma once
+#include "mh_device.hpp"
+
+namespace mh {
+
+// ------------------------------------------------------------------------------------------
+// calibrate
+// ------------------------------------------------------------------------------------------
+struct CalArgs {
+    const uint8_t *data;
+    const uint64_t *ch_off, *ch_len;
+    const uint8_t *sclv;       // K*S lengths
+    const uint32_t *codes;     // K*16 : bit-reversed code | len << 16, by rank
+    uint32_t C, S, h, mode, K;
+    // outputs
+    uint64_t *cutoff;          // may be NULL
+    uint32_t *cal_sorted;      // C*S, may be NULL
+    uint8_t *peak, *enc;       // never NULL (plan scratch when the caller passes NULL)
+    uint2 *lut;                // C*16 {code_rev, len} indexed by min(raw value, 15)
+};
+
+__global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= a.C) return;
+    const int S = (int)a.S;
+    const uint64_t T = a.ch_len[ch];
+    const uint64_t lim = (uint64_t)1 << a.h;
+    const uint64_t c = T < lim ? T : lim;  // functions_1.py:59-64
+    const uint8_t *x = a.data + a.ch_off[ch];
+    uint32_t cnt[MH_LUT_SYMS];
+#pragma unroll
+    for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = 0;
+    for (uint64_t i = lane; i < c; i += 64) {
+        int v = x[i];
+        v = v > S - 1 ? S - 1 : v;  // clip, get_BR_with_approx_sort.py:164
+#pragma unroll
+        for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] += (v == s);
+    }
+#pragma unroll
+    for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = wave_sum_u32(cnt[s]);
+    // every lane now holds the full calibration histogram
+    int p = 0;
+    if (a.mode == MH_MODE_APPROX) {
+        uint32_t best = cnt[0];
+#pragma unroll
+        for (int s = 1; s < MH_LUT_SYMS; ++s)
+            if (s < S && cnt[s] > best) {  // first max wins (np.argmax)
+                best = cnt[s];
+                p = s;
+            }
+    }
+    // calibration histogram in rank order: sorted[k] = cal[symbol_of_rank(k)]
+    uint32_t sorted[MH_LUT_SYMS];
+#pragma unroll
+    for (int k = 0; k < MH_LUT_SYMS; ++k) {
+        const int sym = k < S ? symbol_of_rank((int)a.mode, S, p, k) : 0;
+        uint32_t v = 0;
+#pragma unroll
+        for (int s = 0; s < MH_LUT_SYMS; ++s) v = (s == sym) ? cnt[s] : v;
+        sorted[k] = k < S ? v : 0;
+    }
+    // first argmin over the K encoders of sum_r SCLV[k][r] * sorted[r]  (:254,281)
+    uint32_t best_k = 0;
+    uint64_t best_cost = ~(uint64_t)0;
+    for (uint32_t k = 0; k < a.K; ++k) {
+        uint64_t cost = 0;
+#pragma unroll
+        for (int r = 0; r < MH_LUT_SYMS; ++r)
+            if (r < S) cost += (uint64_t)a.sclv[k * S + r] * sorted[r];
+        if (cost < best_cost) {
+            best_cost = cost;
+            best_k = k;
+        }
+    }
+    if (lane == 0) {
+        if (a.cutoff) a.cutoff[ch] = c;
+        a.peak[ch] = (uint8_t)p;
+        a.enc[ch] = (uint8_t)best_k;
+    }
+    if (a.cal_sorted && lane < S) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < MH_LUT_SYMS; ++k) v = (k == lane) ? sorted[k] : v;
+        a.cal_sorted[(size_t)ch * S + lane] = v;
+    }
+    if (lane < kLut) {
+        const int sym = lane > S - 1 ? S - 1 : lane;
+        const int r = rank_of_symbol((int)a.mode, S, p, sym);
+        const uint32_t e = a.codes[best_k * 16 + r];
+        a.lut[(size_t)ch * kLut + lane] = make_uint2(e & 0xFFFFu, e >> 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// window histogram.  For symbols s = 0..S-2 count the bytes equal to s (the top bin is the
+// window length minus the rest, so no clip pass is needed).  Equality is tested on four
+// bytes at a time with the exact zero-byte trick; match flags accumulate in packed byte
+// counters that are drained with v_sad_u8 every 63 vectors.
+// ------------------------------------------------------------------------------------------
+struct HistArgs {
+    const uint8_t *data;
+    const uint64_t *ch_off;
+    const uint32_t *tile_ch;
+    const uint64_t *tile_start;  // relative to the channel start
+    const uint32_t *tile_n;
+    unsigned long long *hist;    // C*16, zeroed before the launch
+};
+
+template <int NS>
+__device__ __forceinline__ void hist_word(uint32_t x, uint32_t (&acc)[NS])
+{
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t y = x ^ (0x01010101u * (uint32_t)s);
+        const uint32_t t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;  // bit7 set <=> byte != 0
+        acc[s] += (~t >> 7) & 0x01010101u;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_hist(HistArgs a)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint32_t ch = a.tile_ch[tile];
+    const uint8_t *p = a.data + a.ch_off[ch] + a.tile_start[tile];
+    const uint32_t n = a.tile_n[tile];
+    const int tid = threadIdx.x;
+    uint32_t cnt[NS], acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) cnt[s] = acc[s] = 0;
+
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)p & 15)) & 15);
+    head = head < n ? head : n;
+    const uint32_t nvec = (n - head) >> 4;
+    const uint32_t tail = (n - head) & 15;
+    if ((uint32_t)tid < head) {
+        const int b = p[tid];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) cnt[s] += (b == s);
+    }
+    if ((uint32_t)tid < tail) {
+        const int b = p[head + (nvec << 4) + tid];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) cnt[s] += (b == s);
+    }
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(p + head);
+    int pending = 0;
+#pragma unroll 4
+    for (uint32_t i = tid; i < nvec; i += 256) {
+        const u32x4 x = __builtin_nontemporal_load(q + i);
+        hist_word<NS>(x.x, acc);
+        hist_word<NS>(x.y, acc);
+        hist_word<NS>(x.z, acc);
+        hist_word<NS>(x.w, acc);
+        if (++pending == 63) {  // 4 adds of <=1 per byte field and vector: 252 <= 255
+            pending = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                cnt[s] = __builtin_amdgcn_sad_u8(acc[s], 0u, cnt[s]);
+                acc[s] = 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) cnt[s] = __builtin_amdgcn_sad_u8(acc[s], 0u, cnt[s]);
+
+    __shared__ uint32_t red[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t v = wave_sum_u32(cnt[s]);
+        if ((tid & 63) == 0) red[s][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        const uint32_t v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        if (v) atomicAdd(&a.hist[(size_t)ch * kHistStride + tid], (unsigned long long)v);
+    }
+}
+
+struct FinArgs {
+    const unsigned long long *hist;
+    const uint64_t *w0, *w1;
+    const uint8_t *skipflag;
+    const uint8_t *peak, *enc, *sclv;
+    uint32_t C, S, mode;
+    uint64_t *post;   // C*S rank order, may be NULL
+    uint64_t *bits;   // may be NULL
+    uint8_t *skipped; // may be NULL
+};
+
+__global__ __launch_bounds__(256) void k_finalize(FinArgs a)
+{
+    const uint32_t ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= a.C) return;
+    const int S = (int)a.S;
+    const uint64_t n = a.w1[ch] - a.w0[ch];
+    const int p = a.peak[ch];
+    const uint8_t *row = a.sclv + (size_t)a.enc[ch] * S;
+    uint64_t rest = 0, b = 0;
+    for (int s = 0; s < S - 1; ++s) rest += a.hist[(size_t)ch * kHistStride + s];
+    for (int k = 0; k < S; ++k) {
+        const int sym = symbol_of_rank((int)a.mode, S, p, k);
+        const uint64_t v = sym == S - 1 ? n - rest : a.hist[(size_t)ch * kHistStride + sym];
+        if (a.post) a.post[(size_t)ch * S + k] = v;  // get_BR_with_approx_sort.py:193
+        b += (uint64_t)row[k] * v;                    // :289 numerator
+    }
+    if (a.bits) a.bits[ch] = b;
+    if (a.skipped) a.skipped[ch] = a.skipflag[ch];
+}
+
+// ------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------
+struct EncArgs {
+    const uint8_t *data;
+    const uint64_t *ch_off, *w0;
+    const uint32_t *seg_ch;
+    const uint64_t *seg_first, *seg_n, *seg_off;
+    const uint2 *lut;
+    uint32_t *payload;
+    uint64_t *seg_words;
+    unsigned long long *ch_bits;
+    uint32_t nseg;
+    uint32_t stage_dw;  // staging dwords per lane = 8 * maxlen (256 samples * maxlen / 32)
+};
+
+// LDS carve per wave (dwords): [0,32) LUT, then staging [stage_dw][64], then the chunk image
+// [32 header + stage_dw*64 payload]
+__host__ __device__ inline uint32_t enc_wave_dwords(uint32_t stage_dw)
+{
+    return 32 + stage_dw * 64 + 32 + stage_dw * 64;
+}
+
+template <int FI, bool FULL>
+__device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ src, uint32_t m,
+                                             const uint2 *lut, uint32_t *stage, uint32_t *img,
+                                             uint32_t *__restrict__ dst, int lane,
+                                             uint32_t &words, uint32_t &bits)
+{
+    u32x4 v[kRows];
+    int cnt[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const uint32_t base = ((uint32_t)k * kLanes + lane) * MH_PIECE;
+        if (FULL) {
+            v[k] = *reinterpret_cast<const u32x4_u *>(src + base);
+            cnt[k] = MH_PIECE;
+        } else {
+            const int c = (int)m - (int)base;
+            cnt[k] = c < 0 ? 0 : (c > MH_PIECE ? MH_PIECE : c);
+            u32x4 t = {0u, 0u, 0u, 0u};
+            if (cnt[k] == MH_PIECE) {
+                t = *reinterpret_cast<const u32x4_u *>(src + base);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MH_PIECE; ++i)
+                    if (i < cnt[k]) t[i >> 2] |= (uint32_t)src[base + i] << (8 * (i & 3));
+            }
+            v[k] = t;
+        }
+    }
+    // per-lane bit accumulation; every staged dword goes to stage[j*64 + lane]
+    uint64_t acc = 0;
+    uint32_t nb = 0, sp = 0;
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+#pragma unroll
+        for (int i = 0; i < MH_PIECE; ++i) {
+            if (FULL || i < cnt[k]) {
+                uint32_t b = (v[k][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                b = b > 15u ? 15u : b;
+                const uint2 e = lut[b];
+                acc |= (uint64_t)e.x << nb;
+                nb += e.y;
+            }
+            if ((i + 1) % FI == 0 || i == MH_PIECE - 1) {
+                if (nb >= 32) {
+                    stage[sp * 64 + lane] = (uint32_t)acc;
+                    acc >>= 32;
+                    nb -= 32;
+                    ++sp;
+                }
+            }
+        }
+    }
+    const uint32_t tot = sp * 32 + nb;  // exact code bits of this sub-stream
+    if (nb > 0) {
+        stage[sp * 64 + lane] = (uint32_t)acc;
+        ++sp;
+    }
+    // sub-stream placement: exclusive prefix over lanes
+    const uint32_t incl = wave_scan_incl(tot, lane);
+    const uint32_t P = incl - tot;
+    const uint32_t B = __shfl(incl, 63, 64);
+    const uint32_t nw = (B + 31) >> 5;
+    uint32_t *pay = img + kHdrWords;
+    for (uint32_t i = lane; i < nw; i += 64) pay[i] = 0;
+    reinterpret_cast<uint16_t *>(img)[lane] = (uint16_t)tot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = 0; j < sp; ++j) {
+        const uint32_t w = stage[j * 64 + lane];
+        const uint32_t pos = P + 32 * j;
+        const uint64_t sh = (uint64_t)w << (pos & 31);
+        atomicOr(&pay[pos >> 5], (uint32_t)sh);
+        if ((uint32_t)(sh >> 32)) atomicOr(&pay[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t total = kHdrWords + nw;
+    for (uint32_t i = lane; i < total; i += 64) dst[i] = img[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    words = total;
+    bits = B;
+}
+
+template <int FI>
+__global__ __launch_bounds__(256) void k_encode(EncArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (seg >= a.nseg) return;
+    uint32_t *lds = smem + (size_t)wave * enc_wave_dwords(a.stage_dw);
+    uint2 *lut = reinterpret_cast<uint2 *>(lds);
+    uint32_t *stage = lds + 32;
+    uint32_t *img = stage + a.stage_dw * 64;
+    const uint32_t ch = a.seg_ch[seg];
+    if (lane < kLut) lut[lane] = a.lut[(size_t)ch * kLut + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *src = a.data + a.ch_off[ch] + a.w0[ch] + a.seg_first[seg];
+    const uint64_t n = a.seg_n[seg];
+    uint32_t *dst = a.payload + a.seg_off[seg];
+    uint64_t words = 0, bits = 0;
+    for (uint64_t q = 0; q < n; q += kChunk) {
+        const uint64_t left = n - q;
+        uint32_t w, b;
+        if (left >= (uint64_t)kChunk)
+            encode_chunk<FI, true>(src + q, kChunk, lut, stage, img, dst + words, lane, w, b);
+        else
+            encode_chunk<FI, false>(src + q, (uint32_t)left, lut, stage, img, dst + words, lane, w, b);
+        words += w;
+        bits += b;
+    }
+    if (lane == 0) {
+        a.seg_words[seg] = words;
+        atomicAdd(&a.ch_bits[ch], (unsigned long long)bits);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------
+struct DtabArgs {
+    const uint8_t *peak, *enc, *sclv;
+    const uint32_t *codes;
+    uint32_t C, S, mode;
+    uint8_t *dtab;  // C*512 : symbol | len << 4, indexed by the next maxlen stream bits
+    uint8_t *dlen;  // C : maxlen of the channel's encoder
+};
+
+__global__ __launch_bounds__(64) void k_build_dtab(DtabArgs a)
+{
+    const uint32_t ch = blockIdx.x;
+    const int S = (int)a.S, lane = threadIdx.x;
+    const int p = a.peak[ch];
+    const uint32_t k = a.enc[ch];
+    const int L = a.sclv[k * S + S - 1];  // rows are non-decreasing
+    if (lane == 0) a.dlen[ch] = (uint8_t)L;
+    for (int j = lane; j < (1 << L); j += 64) {
+        uint8_t e = 0;
+        for (int r = 0; r < S; ++r) {
+            const uint32_t c = a.codes[k * 16 + r];
+            const int len = (int)(c >> 16);
+            if ((uint32_t)(j & ((1 << len) - 1)) == (c & 0xFFFFu))
+                e = (uint8_t)(symbol_of_rank((int)a.mode, S, p, r) | (len << 4));
+        }
+        a.dtab[(size_t)ch * kDtab + j] = e;
+    }
+}
+
+struct DecArgs {
+    const uint32_t *payload;
+    const uint64_t *ch_off, *w0;
+    const uint32_t *seg_ch;
+    const uint64_t *seg_first, *seg_n, *seg_off;
+    const uint8_t *dtab, *dlen;
+    uint8_t *out;
+    uint32_t nseg;
+};
+
+template <int FI, bool FULL>
+__device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in, uint32_t m,
+                                                 const uint8_t *dtab, uint32_t mask,
+                                                 uint8_t *__restrict__ out, int lane)
+{
+    const uint32_t hw = in[lane >> 1];
+    const uint32_t len = (hw >> (16 * (lane & 1))) & 0xFFFFu;
+    const uint32_t incl = wave_scan_incl(len, lane);
+    const uint32_t P = incl - len;
+    const uint32_t B = __shfl(incl, 63, 64);
+    const uint32_t *pay = in + kHdrWords;
+    uint32_t wi = P >> 5, bp = P & 31;
+    // 64-bit window + one word of read-ahead; reads may run <= 3 words past the chunk
+    uint64_t buf = (uint64_t)pay[wi] | ((uint64_t)pay[wi + 1] << 32);
+    uint32_t nxt = pay[wi + 2];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        const uint32_t base = ((uint32_t)k * kLanes + lane) * MH_PIECE;
+        int cnt = MH_PIECE;
+        if (!FULL) {
+            const int c = (int)m - (int)base;
+            cnt = c < 0 ? 0 : (c > MH_PIECE ? MH_PIECE : c);
+        }
+        u32x4 o = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < MH_PIECE; ++i) {
+            if (FULL || i < cnt) {
+                const uint32_t w = (uint32_t)(buf >> bp) & mask;
+                const uint32_t e = dtab[w];
+                o[i >> 2] |= (e & 15u) << (8 * (i & 3));
+                bp += e >> 4;
+            }
+            if ((i + 1) % FI == 0 || i == MH_PIECE - 1) {
+                if (bp >= 32) {
+                    buf = (buf >> 32) | ((uint64_t)nxt << 32);
+                    bp -= 32;
+                    ++wi;
+                    nxt = pay[wi + 2];
+                }
+            }
+        }
+        if (FULL || cnt == MH_PIECE) {
+            *reinterpret_cast<u32x4_u *>(out + base) = o;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MH_PIECE; ++i)
+                if (i < cnt) out[base + i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+    return kHdrWords + ((B + 31) >> 5);
+}
+
+template <int FI>
+__global__ __launch_bounds__(256) void k_decode(DecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[4][kDtab];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x * 4 + wave;
+    if (seg >= a.nseg) return;
+    const uint32_t ch = a.seg_ch[seg];
+    const int L = a.dlen[ch];
+    uint8_t *tab = tabs[wave];
+    {
+        const uint2 *g = reinterpret_cast<const uint2 *>(a.dtab + (size_t)ch * kDtab);
+        if (lane * 8 < (1 << L) || lane == 0) reinterpret_cast<uint2 *>(tab)[lane] = g[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t mask = (1u << L) - 1u;
+    const uint32_t *in = a.payload + a.seg_off[seg];
+    uint8_t *out = a.out + a.ch_off[ch] + a.w0[ch] + a.seg_first[seg];
+    const uint64_t n = a.seg_n[seg];
+    uint64_t words = 0;
+    for (uint64_t q = 0; q < n; q += kChunk) {
+        const uint64_t left = n - q;
+        if (left >= (uint64_t)kChunk)
+            words += decode_chunk<FI, true>(in + words, kChunk, tab, mask, out + q, lane);
+        else
+            words += decode_chunk<FI, false>(in + words, (uint32_t)left, tab, mask, out + q, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dense re-packing
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_words(const uint64_t *seg_words, uint64_t nseg,
+                                                     uint64_t *dense_off, uint64_t *total)
+{
+    __shared__ uint64_t part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (nseg + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < nseg ? lo + per : nseg;
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += seg_words[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint64_t t = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    uint64_t run = part[tid] - s;
+    for (uint64_t i = lo; i < hi; ++i) {
+        dense_off[i] = run;
+        run += seg_words[i];
+    }
+    if (tid == 1023) total[0] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_compact(const uint32_t *payload, const uint64_t *seg_off,
+                                                 const uint64_t *seg_words,
+                                                 const uint64_t *dense_off, uint32_t *dense,
+                                                 uint64_t dense_cap)
+{
+    const uint32_t seg = blockIdx.x;
+    const uint64_t n = seg_words[seg], d0 = dense_off[seg];
+    if (d0 + n > dense_cap) return;  // host checks total_words afterwards
+    const uint32_t *src = payload + seg_off[seg];
+    uint32_t *dst = dense + d0;
+    for (uint64_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic MUA, re-binning
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t ch, uint64_t q)
+{
+    uint64_t z = (seed + 1) * 0x9E3779B97F4A7C15ULL + ch * 0xD1B54A32D192ED03ULL +
+                 q * 0x8CB92BA72F3D8DD7ULL;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+
+// one thread = one 16-sample piece (4 hashes)
+__global__ __launch_bounds__(256) void k_synth(uint8_t *data, const uint64_t *ch_off,
+                                               const uint64_t *ch_len, uint32_t C,
+                                               const uint32_t *thr, uint64_t seed)
+{
+    for (uint32_t ch = blockIdx.y; ch < C; ch += gridDim.y) {
+        const uint64_t T = ch_len[ch];
+        uint8_t *x = data + ch_off[ch];
+        uint32_t th[15];
+#pragma unroll
+        for (int s = 0; s < 15; ++s) th[s] = thr[(size_t)ch * 15 + s];
+        for (uint64_t pc = (uint64_t)blockIdx.x * 256 + threadIdx.x; pc * 16 < T;
+             pc += (uint64_t)gridDim.x * 256) {
+            u32x4 o = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint64_t z = mix64(seed, ch, pc * 4 + g);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const uint32_t u = (uint32_t)(z >> (16 * f)) & 0xFFFFu;
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int s = 0; s < 15; ++s) v += (u >= th[s]);
+                    o[g] |= v << (8 * f);
+                }
+            }
+            const uint64_t t0 = pc * 16;
+            if (t0 + 16 <= T) {
+                *reinterpret_cast<u32x4_u *>(x + t0) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (t0 + i < T) x[t0 + i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
+            }
+        }
+    }
+}
+
+// out[b] = sum x[b*r .. min(b*r+r, T))  (functions_1.py:11-24 along time, per channel)
+template <bool SAT>
+__global__ __launch_bounds__(256) void k_rebin(const uint8_t *data, const uint64_t *in_off,
+                                               const uint64_t *in_len, uint32_t C, uint32_t r,
+                                               void *out, const uint64_t *out_off)
+{
+    for (uint32_t ch = blockIdx.y; ch < C; ch += gridDim.y) {
+        const uint64_t T = in_len[ch], nb = (T + r - 1) / r;
+        const uint8_t *x = data + in_off[ch];
+        for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < nb;
+             b += (uint64_t)gridDim.x * 256) {
+            const uint64_t t0 = b * r, t1 = t0 + r < T ? t0 + r : T;
+            uint32_t s = 0;
+            for (uint64_t t = t0; t < t1; ++t) s += x[t];
+            if (SAT)
+                reinterpret_cast<uint8_t *>(out)[out_off[ch] + b] = (uint8_t)(s > 255u ? 255u : s);
+            else
+                reinterpret_cast<uint32_t *>(out)[out_off[ch] + b] = s;
+        }
+    }
+}
+
+}  // namespace mh

@@ -1,0 +1,543 @@
+// muahuff.hip -- C ABI (include/muahuff.h) over the gfx950 kernels in mh_kernels.hpp.
+// Host side: argument checking, the segment/tile planner, table upload, kernel launches.
+// There is no CPU fallback anywhere in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mh_kernels.hpp"
+#include "muahuff.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define MH_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(MH_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+uint32_t bitrev(uint32_t v, int n)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
+    return r;
+}
+
+int check_row(const uint8_t *row, int S, uint32_t *maxlen)
+{
+    uint32_t m = 0;
+    for (int r = 0; r < S; ++r) {
+        if (row[r] == 0 || row[r] > 9) return MH_ERR_SCLV;
+        if (r && row[r] < row[r - 1]) return MH_ERR_SCLV;
+        if (row[r] > m) m = row[r];
+    }
+    uint32_t kraft = 0;
+    for (int r = 0; r < S; ++r) kraft += 1u << (m - row[r]);
+    if (kraft != (1u << m)) return MH_ERR_SCLV;
+    *maxlen = m;
+    return MH_OK;
+}
+
+constexpr uint32_t kHistTile = 256 * 16 * 32;  // bytes of one histogram tile (128 KiB)
+
+template <typename T>
+int upload(T **dst, const std::vector<T> &src)
+{
+    const size_t bytes = (src.size() ? src.size() : 1) * sizeof(T);
+    MH_HIP(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (src.size()) MH_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MH_OK;
+}
+
+template <typename T>
+int alloc(T **dst, size_t n)
+{
+    MH_HIP(hipMalloc(reinterpret_cast<void **>(dst), (n ? n : 1) * sizeof(T)));
+    return MH_OK;
+}
+
+int flush_interval(uint32_t maxlen)
+{
+    // symbols between bit-buffer checks so that 31 + FI*maxlen <= 63
+    return maxlen <= 2 ? 16 : maxlen <= 4 ? 8 : maxlen <= 8 ? 4 : 3;
+}
+
+}  // namespace
+
+struct mh_plan {
+    int device = 0;
+    mh_plan_info_t info{};
+    uint64_t max_T = 0;
+    std::vector<uint32_t> seg_ch;
+    std::vector<uint64_t> seg_first, seg_n, seg_off;
+    uint64_t n_tiles = 0;
+    // device tables
+    uint64_t *d_ch_off = nullptr, *d_ch_len = nullptr, *d_w0 = nullptr, *d_w1 = nullptr;
+    uint8_t *d_skip = nullptr, *d_sclv = nullptr;
+    uint32_t *d_codes = nullptr;
+    uint32_t *d_seg_ch = nullptr;
+    uint64_t *d_seg_first = nullptr, *d_seg_n = nullptr, *d_seg_off = nullptr;
+    uint32_t *d_tile_ch = nullptr, *d_tile_n = nullptr;
+    uint64_t *d_tile_start = nullptr;
+    // device scratch
+    unsigned long long *d_hist = nullptr;
+    uint8_t *d_peak = nullptr, *d_enc = nullptr, *d_dtab = nullptr, *d_dlen = nullptr;
+    uint2 *d_lut = nullptr;
+};
+
+static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
+                            uint8_t *peak, uint8_t *enc, hipStream_t st)
+{
+    mh::CalArgs a;
+    a.data = data;
+    a.ch_off = p->d_ch_off;
+    a.ch_len = p->d_ch_len;
+    a.sclv = p->d_sclv;
+    a.codes = p->d_codes;
+    a.C = p->info.C;
+    a.S = p->info.S;
+    a.h = p->info.h;
+    a.mode = p->info.mode;
+    a.K = p->info.K;
+    a.cutoff = cutoff;
+    a.cal_sorted = cal_hist;
+    a.peak = peak;
+    a.enc = enc;
+    a.lut = p->d_lut;
+    hipLaunchKernelGGL(mh::k_calibrate, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+template <int NS>
+static void launch_hist(const mh::HistArgs &a, uint64_t n_tiles, hipStream_t st)
+{
+    hipLaunchKernelGGL(mh::k_hist<NS>, dim3((unsigned)n_tiles), dim3(256), 0, st, a);
+}
+
+template <int FI>
+static int launch_encode(const mh::EncArgs &a, uint32_t waves, hipStream_t st)
+{
+    const size_t lds = (size_t)waves * mh::enc_wave_dwords(a.stage_dw) * sizeof(uint32_t);
+    if (lds > 64 * 1024)
+        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mh::k_encode<FI>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mh::k_encode<FI>, dim3((a.nseg + waves - 1) / waves), dim3(waves * 64), lds, st, a);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+extern "C" {
+
+int mh_version(void) { return MH_VERSION; }
+
+const char *mh_last_error(void) { return g_err; }
+
+int mh_device_info(int device, int *cu_count, uint64_t *hbm_bytes, char *name, int name_cap,
+                   char *arch, int arch_cap)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MH_ERR_NO_DEVICE, "no HIP device visible (libmuahuff has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(MH_ERR_ARG, "device %d out of range (%d)", device, n);
+    hipDeviceProp_t p;
+    MH_HIP(hipGetDeviceProperties(&p, device));
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", p.name);
+    if (arch && arch_cap > 0) snprintf(arch, (size_t)arch_cap, "%s", p.gcnArchName);
+    return MH_OK;
+}
+
+int mh_codebook(const uint8_t *sclv_row, int S, uint16_t *code, uint8_t *len)
+{
+    if (!sclv_row || !code || !len || S < 2 || S > MH_LUT_SYMS) return fail(MH_ERR_ARG, "mh_codebook: bad argument");
+    uint32_t m;
+    if (check_row(sclv_row, S, &m) != MH_OK)
+        return fail(MH_ERR_SCLV, "SCLV row is not a non-decreasing complete prefix-code length vector");
+    uint32_t c = 0;
+    for (int r = 0; r < S; ++r) {
+        if (r) c = (c + 1) << (sclv_row[r] - sclv_row[r - 1]);
+        code[r] = (uint16_t)c;
+        len[r] = sclv_row[r];
+    }
+    return MH_OK;
+}
+
+int mh_approx_sort_perm(int S, int peak, uint8_t *idx)
+{
+    if (!idx || S < 2 || S > MH_LUT_SYMS || peak < 0 || peak >= S)
+        return fail(MH_ERR_ARG, "mh_approx_sort_perm: bad argument");
+    for (int k = 0; k < S; ++k) idx[k] = (uint8_t)mh::symbol_of_rank(MH_MODE_APPROX, S, peak, k);
+    return MH_OK;
+}
+
+int mh_plan_destroy(mh_plan *p)
+{
+    if (!p) return MH_OK;
+    void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_codes,
+                    p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
+                    p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
+                    p->d_dlen, p->d_lut};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+    return MH_OK;
+}
+
+static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len,
+                      const uint8_t *sclv)
+{
+    const mh_plan_info_t &I = p->info;
+    const uint32_t C = I.C, S = I.S, K = I.K;
+    // windows: c = min(2^h, T) (functions_1.py:59-64), e = c + T/2 (get_BR_with_approx_sort.py:180)
+    std::vector<uint64_t> w0(C), w1(C), off(ch_off, ch_off + C), len(ch_len, ch_len + C);
+    std::vector<uint8_t> skip(C, 0);
+    const uint64_t lim = (uint64_t)1 << I.h;
+    uint64_t total = 0, nskip = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+        const uint64_t T = ch_len[c];
+        if (T > p->max_T) p->max_T = T;
+        const uint64_t cut = T < lim ? T : lim, e = cut + T / 2;
+        switch (I.window) {
+        case MH_WIN_REF_HALF:
+            if (e > T) {  // :183-185 skipped, shows up as NaN in the reference
+                skip[c] = 1;
+                w0[c] = w1[c] = cut;
+                ++nskip;
+            } else {
+                w0[c] = cut;
+                w1[c] = e;
+            }
+            break;
+        case MH_WIN_REF_HALF_TRUNC: w0[c] = cut; w1[c] = e > T ? T : e; break;
+        case MH_WIN_AFTER_CAL: w0[c] = cut; w1[c] = T; break;
+        default: w0[c] = 0; w1[c] = T; break;
+        }
+        total += w1[c] - w0[c];
+    }
+    p->info.window_samples = total;
+    p->info.n_skipped = nskip;
+    // segments: seg_chunks chunks each, slot sized for the longest code of any encoder
+    const uint64_t seg_samples = (uint64_t)I.seg_chunks * MH_CHUNK, L = I.maxlen;
+    uint64_t slot = 0;
+    std::vector<uint32_t> tile_ch, tile_n;
+    std::vector<uint64_t> tile_start;
+    for (uint32_t c = 0; c < C; ++c) {
+        const uint64_t n = w1[c] - w0[c];
+        for (uint64_t first = 0; first < n; first += seg_samples) {
+            const uint64_t m = n - first < seg_samples ? n - first : seg_samples;
+            const uint64_t full = m / MH_CHUNK, rem = m % MH_CHUNK;
+            uint64_t words = (full + (rem ? 1 : 0)) * MH_HDR_WORDS + full * ((MH_CHUNK * L + 31) / 32);
+            if (rem) words += (rem * L + 31) / 32;
+            words = (words + 3) & ~(uint64_t)3;
+            p->seg_ch.push_back(c);
+            p->seg_first.push_back(first);
+            p->seg_n.push_back(m);
+            p->seg_off.push_back(slot);
+            slot += words;
+        }
+        for (uint64_t first = 0; first < n; first += kHistTile) {
+            tile_ch.push_back(c);
+            tile_start.push_back(w0[c] + first);
+            tile_n.push_back((uint32_t)(n - first < kHistTile ? n - first : kHistTile));
+        }
+    }
+    p->info.n_segments = p->seg_ch.size();
+    p->info.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
+    p->n_tiles = tile_ch.size();
+    // codebooks by rank: bit-reversed code (first code bit at bit 0) | len << 16
+    std::vector<uint32_t> codes((size_t)K * 16, 0);
+    for (uint32_t k = 0; k < K; ++k) {
+        uint16_t code[16];
+        uint8_t ln[16];
+        int rc = mh_codebook(sclv + (size_t)k * S, (int)S, code, ln);
+        if (rc != MH_OK) return rc;
+        for (uint32_t r = 0; r < S; ++r) codes[k * 16 + r] = bitrev(code[r], ln[r]) | ((uint32_t)ln[r] << 16);
+    }
+    std::vector<uint8_t> sc(sclv, sclv + (size_t)K * S);
+    int rc;
+    if ((rc = upload(&p->d_ch_off, off)) || (rc = upload(&p->d_ch_len, len)) ||
+        (rc = upload(&p->d_w0, w0)) || (rc = upload(&p->d_w1, w1)) || (rc = upload(&p->d_skip, skip)) ||
+        (rc = upload(&p->d_sclv, sc)) || (rc = upload(&p->d_codes, codes)) ||
+        (rc = upload(&p->d_seg_ch, p->seg_ch)) || (rc = upload(&p->d_seg_first, p->seg_first)) ||
+        (rc = upload(&p->d_seg_n, p->seg_n)) || (rc = upload(&p->d_seg_off, p->seg_off)) ||
+        (rc = upload(&p->d_tile_ch, tile_ch)) || (rc = upload(&p->d_tile_n, tile_n)) ||
+        (rc = upload(&p->d_tile_start, tile_start)) ||
+        (rc = alloc(&p->d_hist, (size_t)C * mh::kHistStride)) || (rc = alloc(&p->d_peak, C)) ||
+        (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_dtab, (size_t)C * mh::kDtab)) ||
+        (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)))
+        return rc;
+    return MH_OK;
+}
+
+int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                   uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
+                   uint32_t K, uint32_t seg_chunks)
+{
+    if (!plan || !ch_off || !ch_len || !sclv) return fail(MH_ERR_ARG, "mh_plan_create: NULL argument");
+    *plan = nullptr;
+    if (C == 0) return fail(MH_ERR_ARG, "mh_plan_create: C == 0");
+    if (S < 2 || S > MH_LUT_SYMS) return fail(MH_ERR_ARG, "S=%u outside 2..10", S);
+    if (h > 30) return fail(MH_ERR_ARG, "h=%u outside 0..30", h);
+    if (mode > MH_MODE_APPROX) return fail(MH_ERR_ARG, "mode=%u unknown", mode);
+    if (window > MH_WIN_FULL) return fail(MH_ERR_ARG, "window=%u unknown", window);
+    if (K == 0 || K > 255) return fail(MH_ERR_ARG, "K=%u outside 1..255", K);
+    if (seg_chunks == 0) seg_chunks = 8;
+    uint32_t maxlen = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        uint32_t m;
+        if (check_row(sclv + (size_t)k * S, (int)S, &m) != MH_OK)
+            return fail(MH_ERR_SCLV, "SCLV row %u is not a non-decreasing complete code-length vector", k);
+        if (m > maxlen) maxlen = m;
+    }
+    for (uint32_t c = 0; c < C; ++c)
+        if (ch_len[c] == 0)
+            return fail(MH_ERR_EMPTY_CHANNEL, "channel %u has no bins (the reference raises IndexError)", c);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MH_ERR_NO_DEVICE, "no HIP device visible (libmuahuff has no CPU fallback)");
+    mh_plan *p = new (std::nothrow) mh_plan;
+    if (!p) return fail(MH_ERR_ARG, "out of host memory");
+    MH_HIP(hipGetDevice(&p->device));
+    p->info.C = C;
+    p->info.S = S;
+    p->info.h = h;
+    p->info.mode = mode;
+    p->info.window = window;
+    p->info.K = K;
+    p->info.seg_chunks = seg_chunks;
+    p->info.maxlen = maxlen;
+    const int rc = plan_build(p, ch_off, ch_len, sclv);
+    if (rc != MH_OK) {
+        mh_plan_destroy(p);
+        return rc;
+    }
+    *plan = p;
+    return MH_OK;
+}
+
+int mh_plan_info(const mh_plan *plan, mh_plan_info_t *info)
+{
+    if (!plan || !info) return fail(MH_ERR_ARG, "mh_plan_info: NULL argument");
+    *info = plan->info;
+    return MH_OK;
+}
+
+int mh_plan_segments(const mh_plan *plan, uint32_t *seg_ch, uint64_t *seg_first, uint64_t *seg_n,
+                     uint64_t *seg_off)
+{
+    if (!plan) return fail(MH_ERR_ARG, "mh_plan_segments: NULL plan");
+    const size_t n = plan->seg_ch.size();
+    if (seg_ch && n) memcpy(seg_ch, plan->seg_ch.data(), n * sizeof(uint32_t));
+    if (seg_first && n) memcpy(seg_first, plan->seg_first.data(), n * sizeof(uint64_t));
+    if (seg_n && n) memcpy(seg_n, plan->seg_n.data(), n * sizeof(uint64_t));
+    if (seg_off && n) memcpy(seg_off, plan->seg_off.data(), n * sizeof(uint64_t));
+    return MH_OK;
+}
+
+int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
+               uint8_t *peak, uint8_t *enc, uint64_t *post_hist, uint64_t *bits,
+               uint8_t *skipped, void *stream)
+{
+    if (!p || !data) return fail(MH_ERR_ARG, "mh_measure: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
+    int rc = launch_calibrate(p, data, cutoff, cal_hist, pk, en, st);
+    if (rc) return rc;
+    MH_HIP(hipMemsetAsync(p->d_hist, 0, (size_t)p->info.C * mh::kHistStride * sizeof(unsigned long long), st));
+    if (p->n_tiles) {
+        mh::HistArgs a;
+        a.data = data;
+        a.ch_off = p->d_ch_off;
+        a.tile_ch = p->d_tile_ch;
+        a.tile_start = p->d_tile_start;
+        a.tile_n = p->d_tile_n;
+        a.hist = p->d_hist;
+        switch (p->info.S - 1) {
+        case 1: launch_hist<1>(a, p->n_tiles, st); break;
+        case 2: launch_hist<2>(a, p->n_tiles, st); break;
+        case 3: launch_hist<3>(a, p->n_tiles, st); break;
+        case 4: launch_hist<4>(a, p->n_tiles, st); break;
+        case 5: launch_hist<5>(a, p->n_tiles, st); break;
+        case 6: launch_hist<6>(a, p->n_tiles, st); break;
+        case 7: launch_hist<7>(a, p->n_tiles, st); break;
+        case 8: launch_hist<8>(a, p->n_tiles, st); break;
+        default: launch_hist<9>(a, p->n_tiles, st); break;
+        }
+        MH_HIP(hipGetLastError());
+    }
+    mh::FinArgs f;
+    f.hist = p->d_hist;
+    f.w0 = p->d_w0;
+    f.w1 = p->d_w1;
+    f.skipflag = p->d_skip;
+    f.peak = pk;
+    f.enc = en;
+    f.sclv = p->d_sclv;
+    f.C = p->info.C;
+    f.S = p->info.S;
+    f.mode = p->info.mode;
+    f.post = post_hist;
+    f.bits = bits;
+    f.skipped = skipped;
+    hipLaunchKernelGGL(mh::k_finalize, dim3((f.C + 255) / 256), dim3(256), 0, st, f);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t payload_cap_words,
+              uint64_t *seg_words, uint64_t *ch_bits, uint8_t *peak, uint8_t *enc,
+              uint8_t *skipped, void *stream)
+{
+    if (!p || !data || !payload || !seg_words || !ch_bits)
+        return fail(MH_ERR_ARG, "mh_encode: NULL argument");
+    if (payload_cap_words < p->info.payload_cap_words)
+        return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
+                    (unsigned long long)payload_cap_words,
+                    (unsigned long long)p->info.payload_cap_words);
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
+    int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st);
+    if (rc) return rc;
+    MH_HIP(hipMemsetAsync(ch_bits, 0, (size_t)p->info.C * sizeof(uint64_t), st));
+    if (skipped)
+        MH_HIP(hipMemcpyAsync(skipped, p->d_skip, p->info.C, hipMemcpyDeviceToDevice, st));
+    if (p->info.n_segments == 0) return MH_OK;
+    mh::EncArgs a;
+    a.data = data;
+    a.ch_off = p->d_ch_off;
+    a.w0 = p->d_w0;
+    a.seg_ch = p->d_seg_ch;
+    a.seg_first = p->d_seg_first;
+    a.seg_n = p->d_seg_n;
+    a.seg_off = p->d_seg_off;
+    a.lut = p->d_lut;
+    a.payload = payload;
+    a.seg_words = seg_words;
+    a.ch_bits = reinterpret_cast<unsigned long long *>(ch_bits);
+    a.nseg = (uint32_t)p->info.n_segments;
+    a.stage_dw = 8 * p->info.maxlen;
+    // waves per workgroup: as many as fit 160 KiB of LDS, at most 4
+    const size_t per_wave = (size_t)mh::enc_wave_dwords(a.stage_dw) * sizeof(uint32_t);
+    uint32_t waves = (uint32_t)((160 * 1024) / per_wave);
+    waves = waves > 4 ? 4 : (waves < 1 ? 1 : waves);
+    switch (flush_interval(p->info.maxlen)) {
+    case 16: return launch_encode<16>(a, waves, st);
+    case 8: return launch_encode<8>(a, waves, st);
+    case 4: return launch_encode<4>(a, waves, st);
+    default: return launch_encode<3>(a, waves, st);
+    }
+}
+
+int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, const uint8_t *peak,
+              const uint8_t *enc, uint8_t *out, void *stream)
+{
+    if (!p || !payload || !peak || !enc || !out) return fail(MH_ERR_ARG, "mh_decode: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    mh::DtabArgs t;
+    t.peak = peak;
+    t.enc = enc;
+    t.sclv = p->d_sclv;
+    t.codes = p->d_codes;
+    t.C = p->info.C;
+    t.S = p->info.S;
+    t.mode = p->info.mode;
+    t.dtab = p->d_dtab;
+    t.dlen = p->d_dlen;
+    hipLaunchKernelGGL(mh::k_build_dtab, dim3(t.C), dim3(64), 0, st, t);
+    MH_HIP(hipGetLastError());
+    if (p->info.n_segments == 0) return MH_OK;
+    mh::DecArgs a;
+    a.payload = payload;
+    a.ch_off = p->d_ch_off;
+    a.w0 = p->d_w0;
+    a.seg_ch = p->d_seg_ch;
+    a.seg_first = p->d_seg_first;
+    a.seg_n = p->d_seg_n;
+    a.seg_off = seg_off ? seg_off : p->d_seg_off;
+    a.dtab = p->d_dtab;
+    a.dlen = p->d_dlen;
+    a.out = out;
+    a.nseg = (uint32_t)p->info.n_segments;
+    const dim3 grid((a.nseg + 3) / 4), block(256);
+    switch (flush_interval(p->info.maxlen)) {
+    case 16: hipLaunchKernelGGL(mh::k_decode<16>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(mh::k_decode<8>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(mh::k_decode<4>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(mh::k_decode<3>, grid, block, 0, st, a); break;
+    }
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, uint32_t *dense,
+               uint64_t dense_cap_words, uint64_t *dense_off, uint64_t *total_words, void *stream)
+{
+    if (!p || !payload || !seg_words || !dense || !dense_off || !total_words)
+        return fail(MH_ERR_ARG, "mh_compact: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t nseg = p->info.n_segments;
+    hipLaunchKernelGGL(mh::k_scan_words, dim3(1), dim3(1024), 0, st, seg_words, nseg, dense_off, total_words);
+    MH_HIP(hipGetLastError());
+    if (nseg) {
+        hipLaunchKernelGGL(mh::k_compact, dim3((unsigned)nseg), dim3(256), 0, st, payload,
+                           (const uint64_t *)p->d_seg_off, seg_words, (const uint64_t *)dense_off,
+                           dense, dense_cap_words);
+        MH_HIP(hipGetLastError());
+    }
+    return MH_OK;
+}
+
+int mh_synth_poisson(uint8_t *data, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                     uint64_t max_len, const uint32_t *thr, uint64_t seed, void *stream)
+{
+    if (!data || !ch_off || !ch_len || !thr || C == 0) return fail(MH_ERR_ARG, "mh_synth_poisson: bad argument");
+    uint64_t bx = (max_len + 256 * 16 - 1) / (256 * 16);
+    if (bx == 0) bx = 1;
+    if (bx > 4096) bx = 4096;
+    const uint32_t by = C > 65535 ? 65535 : C;
+    hipLaunchKernelGGL(mh::k_synth, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, data,
+                       ch_off, ch_len, C, thr, seed);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len, uint32_t C,
+             uint64_t max_len, uint32_t r, int saturate, void *out, const uint64_t *out_off,
+             void *stream)
+{
+    if (!data || !in_off || !in_len || !out || !out_off || C == 0 || r == 0)
+        return fail(MH_ERR_ARG, "mh_rebin: bad argument");
+    uint64_t bx = ((max_len + r - 1) / r + 255) / 256;
+    if (bx == 0) bx = 1;
+    if (bx > 4096) bx = 4096;
+    const uint32_t by = C > 65535 ? 65535 : C;
+    if (saturate)
+        hipLaunchKernelGGL(mh::k_rebin<true>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
+                           data, in_off, in_len, C, r, out, out_off);
+    else
+        hipLaunchKernelGGL(mh::k_rebin<false>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
+                           data, in_off, in_len, C, r, out, out_off);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+"""Multi-GPU: channels shard across ranks (one process per GPU); the only exchange is the
+gather that concatenates the packed bitstreams on rank 0 (RCCL over xGMI; ``gloo`` on CPU in
+tests).  Channels are independent (per-channel calibration, codebook choice and bitstream,
+SURVEY.md section 8e), so measure / encode / decode need no collective at all.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_channels(C, world_size, rank):
+    """Contiguous channel block [lo, hi) of this rank; the first C % world ranks get one more."""
+    base, extra = divmod(int(C), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_metadata(tensors, dst=0, group=None):
+    """Gather small fixed-size per-channel arrays (bit lengths, peak, enc ...) of every rank on
+    ``dst``.  tensors: dict name -> tensor (same dtype per name on all ranks; lengths may
+    differ).  Returns dict name -> list of per-rank tensors on dst, None elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out = {}
+    for name, t in tensors.items():
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=group)
+        sizes = [int(s.item()) for s in sizes]
+        m = max(sizes) if sizes else 0
+        pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+        pad[:t.numel()] = t.reshape(-1)
+        bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, bufs, dst=dst, group=group)
+        out[name] = [b[:s] for b, s in zip(bufs, sizes)] if rank == dst else None
+    return out
+
+
+def gather_payload(dense, total_words, dst=0, group=None):
+    """Concatenate the dense payloads of all ranks on ``dst`` in rank (= channel) order.
+
+    dense: int32 words of this rank (only the first total_words are sent).  Every peer sends
+    its shard over its own xGMI link to the root concurrently (point-to-point, no ring), which
+    is the cheapest pattern for a gather on a full mesh.  Returns (payload, word offsets per
+    rank) on dst and (None, offsets) elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([int(total_words)], dtype=torch.int64, device=dense.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    if rank == dst:
+        out = torch.empty(int(offs[-1]) + 4, dtype=dense.dtype, device=dense.device)
+        out[offs[rank]:offs[rank + 1]] = dense[:sizes[rank]]
+        ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group) for r in range(world)
+               if r != dst and sizes[r] > 0]
+    else:
+        out = None
+        ops = [dist.P2POp(dist.isend, dense[:sizes[rank]], dst, group)] if sizes[rank] > 0 else []
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out, offs

@@ -1,0 +1,168 @@
+/*
+ * muahuff.h -- C ABI of libmuahuff.so, the MI355X (gfx950) data plane for static-Huffman
+ * compression of binned multi-channel MUA spike counts.
+ *
+ * The reference (zhengzhang96/Hardware-efficient-MUA-compression) has NO FFI or plugin
+ * interface: its hot path is a set of NumPy statements inside three scripts.  Each entry
+ * point below therefore cites the reference statements it replaces (paths relative to the
+ * reference checkout, directory names contain spaces).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns MH_OK (0) or a negative MH_ERR_* code and never throws;
+ *     mh_last_error() returns a thread-local message for the last failure on this thread;
+ *   - "host" pointers are plain host memory read synchronously during the call;
+ *     "device" pointers are HIP device pointers (e.g. torch.Tensor.data_ptr()); the caller
+ *     allocates and owns every buffer;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); device work is
+ *     enqueued asynchronously on it and nothing in mh_measure/mh_encode/mh_decode/
+ *     mh_compact/mh_synth_poisson/mh_rebin synchronises, allocates or frees, so they can
+ *     be captured into a hipGraph;
+ *   - a plan is bound to the device that was current when it was created and may be used
+ *     from one stream at a time (it owns per-channel scratch tables).
+ */
+#ifndef MUAHUFF_H
+#define MUAHUFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_VERSION 100 /* 0.1.0 ; container format revision 1 */
+
+/* ---- error codes -------------------------------------------------------------------- */
+#define MH_OK 0
+#define MH_ERR_ARG (-1)           /* NULL pointer, S/h/K out of range, ... */
+#define MH_ERR_EMPTY_CHANNEL (-2) /* a channel with 0 bins: the reference raises IndexError
+                                     (Compressing data/functions_1.py:45, data_in[0]) */
+#define MH_ERR_SCLV (-3)          /* SCLV row not non-decreasing / Kraft sum != 1 */
+#define MH_ERR_CAPACITY (-4)      /* payload buffer smaller than mh_plan_info.payload_cap_words */
+#define MH_ERR_HIP (-5)           /* a HIP runtime call failed (message has the HIP error) */
+#define MH_ERR_NO_DEVICE (-6)     /* no gfx950 device visible: there is NO CPU fallback */
+
+/* ---- container geometry (format revision 1; the reference has no bitstream, so this is
+ *      build-defined -- see DESIGN.md "Container") ----------------------------------- */
+#define MH_PIECE 16                        /* samples per piece (one 16-byte vector)          */
+#define MH_LANES 64                        /* sub-streams per chunk = lanes of a wavefront    */
+#define MH_ROWS 16                         /* pieces per sub-stream                           */
+#define MH_SUB (MH_PIECE * MH_ROWS)        /* 256 samples per sub-stream                      */
+#define MH_CHUNK (MH_SUB * MH_LANES)       /* 16384 samples per chunk                         */
+#define MH_HDR_WORDS (MH_LANES / 2)        /* chunk header: 64 x u16 sub-stream bit lengths   */
+
+/* mapper: which symbol -> rank permutation the calibration yields */
+#define MH_MODE_NOSORT 0 /* identity          Compressing data/get_BR_no_sort.py:174,192        */
+#define MH_MODE_APPROX 1 /* approx_sort       Compressing data/functions_1.py:75-90             */
+
+/* measured / encoded window of a channel of T bins with calibration cutoff c = min(2^h,T) */
+#define MH_WIN_REF_HALF 0       /* [c, c+T/2); channel skipped when c+T/2 > T
+                                   (Compressing data/get_BR_with_approx_sort.py:180-189)       */
+#define MH_WIN_REF_HALF_TRUNC 1 /* [c, min(c+T/2,T)), never skipped
+                                   (Compressing data/test_chosen_system.py:99-103)             */
+#define MH_WIN_AFTER_CAL 2      /* [c, T)  : compress everything after calibration             */
+#define MH_WIN_FULL 3           /* [0, T)  : whole channel (training histograms,
+                                   Compressing data/get_BR_with_approx_sort.py:140-147)        */
+
+typedef struct mh_plan mh_plan; /* opaque */
+
+typedef struct {
+    uint32_t C, S, h, mode, window, K, seg_chunks, maxlen;
+    uint64_t n_segments;        /* directory entries                                           */
+    uint64_t payload_cap_words; /* u32 words the encode payload buffer must hold               */
+    uint64_t window_samples;    /* sum over channels of the window length                      */
+    uint64_t n_skipped;         /* channels skipped by the MH_WIN_REF_HALF rule                */
+} mh_plan_info_t;
+
+/* ---- library / device --------------------------------------------------------------- */
+int mh_version(void);
+const char *mh_last_error(void);
+/* properties of HIP device `device`; any output pointer may be NULL */
+int mh_device_info(int device, int *cu_count, uint64_t *hbm_bytes, char *name, int name_cap,
+                   char *arch, int arch_cap);
+
+/* ---- host-side helpers (no GPU needed) ----------------------------------------------- */
+/* Canonical codewords (MSB-first values) of one sorted codeword-length vector; rank 0 gets
+ * the shortest code.  S=3, [1,2,2] -> 0,10,11 == Compressing data/test_chosen_system.py:26.
+ * Lengths come from Compressing data/Produce SCLVs/Stored_SCLVs_S_<S>.pkl. */
+int mh_codebook(const uint8_t *sclv_row, int S, uint16_t *code, uint8_t *len);
+/* idx[k] = symbol that gets rank k for a calibration histogram peaking at `peak`:
+ * the result of Compressing data/functions_1.py:75-90 (approx_sort), closed form. */
+int mh_approx_sort_perm(int S, int peak, uint8_t *idx);
+
+/* ---- plan ---------------------------------------------------------------------------- */
+/* Describes a set of C channels laid out channel-major in one uint8 device buffer
+ * (channel i = bytes [ch_off[i], ch_off[i]+ch_len[i]) ; the in-memory form of
+ * all_binned_data[BP][dataset][channel], Data/get_all_binned_data.py:62-64) and fixes the
+ * design point: S (symbols 0..S-1), h (calibration window 2^h samples), mapper mode,
+ * window rule, K candidate encoders given as SCLV rows (host, K*S bytes, row order =
+ * encoder index, first-min tie-break as np.argmin).  Precomputes windows, the segment
+ * directory and codebooks and uploads them.  ch_off, ch_len, sclv: host. */
+int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                   uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
+                   uint32_t K, uint32_t seg_chunks);
+int mh_plan_destroy(mh_plan *plan);
+int mh_plan_info(const mh_plan *plan, mh_plan_info_t *info);
+/* host copies of the segment directory (each array n_segments long, any may be NULL):
+ * channel, first sample (relative to the window start), sample count, slot offset (words) */
+int mh_plan_segments(const mh_plan *plan, uint32_t *seg_ch, uint64_t *seg_first,
+                     uint64_t *seg_n, uint64_t *seg_off);
+
+/* ---- device operations ---------------------------------------------------------------- */
+/* Everything the reference computes per validation channel at one (S, h):
+ *   clip                       get_BR_with_approx_sort.py:164
+ *   cutoff c                   functions_1.py:27-68  (== min(2^h, T))
+ *   calibration histogram      get_BR_with_approx_sort.py:171
+ *   peak / permutation         functions_1.py:75-90 ; identity for MH_MODE_NOSORT
+ *   encoder = first argmin     get_BR_with_approx_sort.py:254,281
+ *   window + post histogram    get_BR_with_approx_sort.py:180-193
+ *   bits = SCLV[enc].post      get_BR_with_approx_sort.py:289 (numerator)
+ * Outputs (device, any may be NULL): cutoff[C]; cal_hist[C*S] and post_hist[C*S] in RANK
+ * order (what the reference stores in val_histograms / val_histograms_post); peak[C];
+ * enc[C]; bits[C]; skipped[C] (post_hist row is all zero and bits 0 for a skipped channel,
+ * which the reference's float formula turns into NaN). */
+int mh_measure(mh_plan *plan, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
+               uint8_t *peak, uint8_t *enc, uint64_t *post_hist, uint64_t *bits,
+               uint8_t *skipped, void *stream);
+
+/* Calibrate every channel as mh_measure does, then emit the window of each channel as a
+ * static-Huffman bitstream (NEW work: the reference only multiplies histograms by code
+ * lengths, get_BR_with_approx_sort.py:133-137).  Segment s is written at word offset
+ * seg_off[s] (mh_plan_segments) of `payload`; seg_words[s] receives the words used.
+ * ch_bits[c] = exact code bits of channel c == the reference's SCLV[enc].post_hist. */
+int mh_encode(mh_plan *plan, const uint8_t *data, uint32_t *payload, uint64_t payload_cap_words,
+              uint64_t *seg_words, uint64_t *ch_bits, uint8_t *peak, uint8_t *enc,
+              uint8_t *skipped, void *stream);
+
+/* Inverse of mh_encode: writes clip(x) = min(x, S-1) for every window sample into `out`
+ * (same channel layout as the plan's data buffer; bytes outside the windows are left
+ * untouched).  seg_off (device, words) = where each segment starts in `payload`; NULL means
+ * the plan's slot offsets.  payload must stay readable 4 words past the last segment. */
+int mh_decode(mh_plan *plan, const uint32_t *payload, const uint64_t *seg_off,
+              const uint8_t *peak, const uint8_t *enc, uint8_t *out, void *stream);
+
+/* Pack the used words of all segments back to back (directory order) for storage or for
+ * the RCCL gather: dense_off[s] = exclusive prefix of seg_words, total_words[0] = sum. */
+int mh_compact(mh_plan *plan, const uint32_t *payload, const uint64_t *seg_words,
+               uint32_t *dense, uint64_t dense_cap_words, uint64_t *dense_off,
+               uint64_t *total_words, void *stream);
+
+/* Synthetic Poisson-like MUA: x[ch][t] = #{s<15 : u16(seed,ch,t) >=
+ * thr[ch*15+s]}, u16 from a splitmix64-finalised counter.  ch_off/ch_len/thr: device. */
+int mh_synth_poisson(uint8_t *data, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                     uint64_t max_len, const uint32_t *thr, uint64_t seed, void *stream);
+
+/* Per-channel re-binning: out[b] = sum of x[b*r .. min(b*r+r,T))
+ * (Compressing data/functions_1.py:11-24, bin_MUA_data, applied along time).
+ * saturate != 0: uint8 output saturating at 255 like MATLAB uint8()
+ * (Data/Load_and_bin_Sabes_store_as_mat_file.m:53); else uint32 output.
+ * in_off/in_len/out_off: device arrays of C entries (out_off in output elements). */
+int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len, uint32_t C,
+             uint64_t max_len, uint32_t r, int saturate, void *out, const uint64_t *out_off,
+             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUAHUFF_H */

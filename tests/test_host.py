@@ -1,0 +1,117 @@
+"""CPU-side checks of the product: tables, the functions_1 drop-in, and that libmuahuff.so
+loads and exports exactly what include/muahuff.h declares.  No GPU, no compute calls."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+import muahuff
+from muahuff import _lib, sclv
+from muahuff import functions_1 as f1
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "muahuff.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mh_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    raw = ct.CDLL(_lib.SO)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert _lib.lib().mh_version() == 100
+
+
+def test_geometry_constants_match_header():
+    hdr = open(os.path.join(ROOT, "include", "muahuff.h")).read()
+    for name, val in (("MH_PIECE", _lib.PIECE), ("MH_LANES", _lib.LANES), ("MH_ROWS", _lib.ROWS)):
+        assert int(re.search(r"#define %s (\d+)" % name, hdr).group(1)) == val
+    assert _lib.CHUNK == 16384 and _lib.HDR_WORDS == 32
+
+
+def test_sclv_tables_equal_reference_pickles():
+    gold = helpers.sclv_tables()
+    for S in range(2, 11):
+        assert np.array_equal(sclv.table(S), gold[S]), S
+
+
+def test_codebook_host_helper():
+    assert sclv.codewords([1, 2, 2]) == ["0", "10", "11"]  # test_chosen_system.py:26
+    assert sclv.codewords([1, 2, 3, 4, 4]) == ["0", "10", "110", "1110", "1111"]
+    with pytest.raises(muahuff.MuaHuffError) as e:
+        sclv.codebook([1, 1, 2])
+    assert e.value.code == _lib.ERR_SCLV
+
+
+def test_approx_sort_perm_abi_and_dropin():
+    t = helpers.tables()
+    for S in range(2, 11):
+        for p in range(S):
+            want = t["approx_sort"][str(S)][p]
+            idx = np.zeros(S, np.uint8)
+            _lib.check(_lib.lib().mh_approx_sort_perm(S, p, idx.ctypes.data))
+            assert list(idx) == want
+            hist = np.ones(S, dtype=np.int64)
+            hist[p] = 7
+            got_idx, got_sorted = f1.approx_sort(hist)
+            assert list(got_idx) == want and got_idx.dtype == int
+            assert np.array_equal(got_sorted, hist[want])
+    for rec in t["approx_sort_ties"]:
+        got_idx, _ = f1.approx_sort(np.array(rec["hist"]))
+        assert list(got_idx) == rec["idx"]
+
+
+def test_online_histogram_dropin():
+    for rec in helpers.tables()["cutoff"]:
+        x = np.array(rec["x"], dtype=np.uint8)
+        hist, i = f1.online_histogram_w_sat_based_nb_of_samples(x, rec["cutoff"], rec["S"] - 1)
+        assert i == rec["i"]
+        assert list(x) == rec["x_after"]
+        assert sum(hist.values()) == i and "0" in hist
+        clipped = np.minimum(np.array(rec["x"][:i]), rec["S"] - 1)
+        for k, v in hist.items():
+            assert v == int((clipped == int(k)).sum())
+    with pytest.raises(IndexError):
+        f1.online_histogram_w_sat_based_nb_of_samples(np.zeros(0, np.uint8), 4, 2)
+
+
+def test_module_surface_matches_reference():
+    # from functions_1 import * must give the three functions plus np and math
+    ns = {}
+    exec("from muahuff.functions_1 import *", ns)
+    for name in ("bin_MUA_data", "online_histogram_w_sat_based_nb_of_samples", "approx_sort", "np", "math"):
+        assert name in ns
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from muahuff import codec
+    with pytest.raises(muahuff.MuaHuffError):
+        codec.Plan(np.zeros(1, np.uint64), np.full(1, 100, np.uint64), 3, 6, 1, 0, sclv.table(3))
+    # and straight through the C ABI: plan creation refuses, it does not fall back
+    h = ct.c_void_p()
+    off, ln, tab = np.zeros(1, np.uint64), np.full(1, 100, np.uint64), sclv.table(3)
+    rc = _lib.lib().mh_plan_create(ct.byref(h), off.ctypes.data, ln.ctypes.data, 1, 3, 6, 1, 0,
+                                   tab.ctypes.data, 1, 8)
+    assert rc == _lib.ERR_NO_DEVICE and not h.value
+
+
+def test_plan_argument_errors_without_gpu():
+    h = ct.c_void_p()
+    off, tab = np.zeros(1, np.uint64), sclv.table(3)
+    rc = _lib.lib().mh_plan_create(ct.byref(h), off.ctypes.data, np.zeros(1, np.uint64).ctypes.data, 1, 3, 6,
+                                   1, 0, tab.ctypes.data, 1, 8)
+    assert rc == _lib.ERR_EMPTY_CHANNEL  # the reference raises IndexError on an empty channel
+    rc = _lib.lib().mh_plan_create(ct.byref(h), off.ctypes.data, np.ones(1, np.uint64).ctypes.data, 1, 11, 6,
+                                   1, 0, tab.ctypes.data, 1, 8)
+    assert rc == _lib.ERR_ARG
+    bad = np.array([[2, 1, 2]], np.uint8)
+    rc = _lib.lib().mh_plan_create(ct.byref(h), off.ctypes.data, np.ones(1, np.uint64).ctypes.data, 1, 3, 6,
+                                   1, 0, bad.ctypes.data, 1, 8)
+    assert rc == _lib.ERR_SCLV
