@@ -1,0 +1,443 @@
+// mh_codec2.hpp -- second-generation encode / decode kernels (same container format).
+//
+// A workgroup (4 waves) owns up to 4 consecutive segments OF ONE CHANNEL, so the channel's
+// tables sit once per workgroup at a fixed LDS address:
+//   encode: 256-entry PAIR table {code, len} indexed by two clipped symbols (b0 | b1 << 4);
+//           two symbols per LDS lookup, two lookups merged in 32-bit before they touch the
+//           lane's 64-bit accumulator.  When no byte of a 16-byte piece exceeds 15 (checked
+//           once per piece per wave) the two indices of a dword come from x | x >> 4 with no
+//           per-byte clipping.
+//   decode: multi-symbol table, one lookup yields up to 4 symbols already spread to bytes
+//           {4 symbol bytes, n | bits << 8}; for S <= 3 (maxlen <= 2) every 8-bit window
+//           holds >= 4 symbols, so one lookup == one output dword.  The chunk payload is
+//           staged in LDS with coalesced loads; the symbol loop touches no global memory
+//           except its 16-byte output stores.
+// Partial (last) chunks of a channel go through the first-generation per-symbol routines.
+#pragma once
+#include "mh_kernels.hpp"
+
+namespace mh {
+
+struct TaskArgs {
+    const uint32_t *task_seg0;  // first segment of the task
+    const uint8_t *task_n;      // segments in the task (1..4), all of one channel
+    uint32_t ntask;
+};
+
+// ------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------
+struct Enc2Args {
+    EncArgs e;
+    TaskArgs t;
+};
+
+constexpr uint32_t kEncSharedDw = 512 + 32;  // pair table (256 x uint2) + single table (16 x uint2)
+
+__host__ __device__ inline uint32_t enc2_wave_dwords(uint32_t stage_dw)
+{
+    return stage_dw * 64 + 64 + 32 + stage_dw * 64;  // staging + (carried tail + chunk image)
+}
+
+// LC: 0 maxlen<=2 (flush check per piece), 1 maxlen<=4 (per 2 dwords), 2 maxlen<=8 (per dword),
+//     3 maxlen==9 (per pair, no 32-bit quad merge)
+// PB: bits per symbol in the pair index.  PB=3 (S<=8) keeps the hot entries (small symbols) on
+//     distinct LDS banks; PB=4 (S=9,10) xor-swizzles the index for the same reason.
+constexpr int kWin = 8;  // rows (1 KiB each) a wave keeps in flight
+
+template <int PB>
+__device__ __forceinline__ uint32_t pair_index_word(uint32_t x)
+{
+    // byte0 = b0 | b1 << PB, byte2 = b2 | b3 << PB  (requires every byte < 2^PB)
+    uint32_t y = x | (x >> (8 - PB));
+    if (PB == 4) y ^= (y >> 3) & 0x1F1F1F1Fu;  // bijective on each byte
+    return y;
+}
+
+template <int PB>
+__device__ __forceinline__ uint32_t clip_word(uint32_t d)
+{
+    const uint32_t lim = (1u << PB) - 1u;
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t b = (d >> (8 * i)) & 0xFFu;
+        b = b > lim ? lim : b;
+        r |= b << (8 * i);
+    }
+    return r;
+}
+
+__device__ __forceinline__ u32x4 load_row(const uint8_t *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
+}
+
+// One full chunk.  v[] is a rolling window: row k of this chunk sits in v[k & 7]; after it is
+// consumed the slot is refilled with the row 8 KiB further on (this chunk, then the next one).
+// ABL (debug ablation, 0 in production): 1 no global stores, 2 also no merge, 3 also no staging
+// writes, 4 loads only
+template <int LC, int PB, int ABL = 0>
+__device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_t *__restrict__ cur,
+                                                  bool has_next, const uint2 *lut2, uint32_t *stage,
+                                                  uint32_t *img, uint32_t *__restrict__ &dst,
+                                                  uint32_t &pend, int lane, uint32_t &words,
+                                                  uint32_t &bits)
+{
+    uint64_t acc = 0;
+    uint32_t nb = 0, sp = 0;
+    constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
+#define MH_FLUSH()                                            \
+    if (nb >= 32) {                                           \
+        if (ABL < 3) stage[sp * 64 + lane] = (uint32_t)acc;   \
+        acc >>= 32;                                           \
+        nb -= 32;                                             \
+        ++sp;                                                 \
+    }
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        u32x4 x = v[k & (kWin - 1)];
+        if (k < kRows - kWin || has_next)
+            v[k & (kWin - 1)] = load_row(cur + ((uint32_t)(k + kWin) * kLanes + lane) * MH_PIECE);
+        if (ABL == 4) {
+            acc += x.x ^ x.y ^ x.z ^ x.w;
+            continue;
+        }
+        const uint32_t hi = (x.x | x.y | x.z | x.w) & kHiMask;
+        if (__any(hi != 0)) {  // rare: a count that does not fit PB bits somewhere in this KiB row
+            x.x = clip_word<PB>(x.x);
+            x.y = clip_word<PB>(x.y);
+            x.z = clip_word<PB>(x.z);
+            x.w = clip_word<PB>(x.w);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t y = pair_index_word<PB>(x[d]);
+            const uint2 e0 = lut2[y & 0xFFu];
+            const uint2 e1 = lut2[(y >> 16) & 0xFFu];
+            if (LC == 3) {
+                acc |= (uint64_t)e0.x << nb;
+                nb += e0.y;
+                MH_FLUSH();
+                acc |= (uint64_t)e1.x << nb;
+                nb += e1.y;
+                MH_FLUSH();
+            } else {
+                const uint32_t q = e0.x | (e1.x << e0.y);
+                acc |= (uint64_t)q << nb;
+                nb += e0.y + e1.y;
+                if (LC == 2 || (LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
+            }
+        }
+    }
+#undef MH_FLUSH
+    if (ABL >= 2) {  // keep the work alive, skip the rest
+        words = 0;
+        bits = (uint32_t)acc + nb + sp;
+        return;
+    }
+    const uint32_t tot = sp * 32 + nb;
+    if (nb > 0) {
+        stage[sp * 64 + lane] = (uint32_t)acc;
+        ++sp;
+    }
+    const uint32_t incl = wave_scan_incl(tot, lane);
+    const uint32_t P = incl - tot;
+    const uint32_t B = __shfl(incl, 63, 64);
+    const uint32_t nw = (B + 31) >> 5;
+    // The chunk image is built right behind the `pend` words carried over from the previous
+    // chunk, so that only whole, 256-byte-aligned blocks ever go to HBM (16 B per lane).
+    uint32_t *hdr = img + pend;
+    uint32_t *pay = hdr + kHdrWords;
+    for (uint32_t i = lane; i < nw; i += 64) pay[i] = 0;
+    reinterpret_cast<uint16_t *>(hdr)[lane] = (uint16_t)tot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = 0; j < sp; ++j) {
+        const uint32_t w = stage[j * 64 + lane];
+        const uint32_t pos = P + 32 * j;
+        const uint64_t sh = (uint64_t)w << (pos & 31);
+        atomicOr(&pay[pos >> 5], (uint32_t)sh);
+        if ((uint32_t)(sh >> 32)) atomicOr(&pay[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t total = pend + kHdrWords + nw;
+    const uint32_t nflush = total & ~63u;
+    if (ABL < 1)
+        for (uint32_t i = lane * 4; i < nflush; i += 256)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(img + i),
+                                        reinterpret_cast<u32x4 *>(dst + i));
+    const uint32_t tail = total - nflush;
+    uint32_t t = 0;
+    if ((uint32_t)lane < tail) t = img[nflush + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)lane < tail) img[lane] = t;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    dst += nflush;
+    pend = tail;
+    words = kHdrWords + nw;
+    bits = B;
+}
+
+template <int LC, int PB, int ABL = 0>
+__global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x;
+    const uint32_t seg0 = a.t.task_seg0[task];
+    const uint32_t nseg = a.t.task_n[task];
+    const uint32_t ch = a.e.seg_ch[seg0];
+    uint2 *lut2 = reinterpret_cast<uint2 *>(smem);
+    uint2 *lut1 = reinterpret_cast<uint2 *>(smem + 512);
+    {   // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
+        const uint2 *g = a.e.lut + (size_t)ch * kLut;
+        const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
+        if (threadIdx.x < (1u << (2 * PB))) {
+            const uint2 ea = g[b0], eb = g[b1];
+            uint32_t idx = b0 | (b1 << PB);
+            if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
+            lut2[idx] = make_uint2(ea.x | (eb.x << ea.y), ea.y + eb.y);
+        }
+        if (threadIdx.x < kLut) lut1[threadIdx.x] = g[threadIdx.x];
+    }
+    __syncthreads();
+    if ((uint32_t)wave >= nseg) return;
+    const uint32_t seg = seg0 + wave;
+    uint32_t *lds = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(a.e.stage_dw);
+    uint32_t *stage = lds;
+    uint32_t *img = stage + a.e.stage_dw * 64;
+    const uint8_t *src = a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg];
+    const uint64_t n = a.e.seg_n[seg];
+    uint32_t *dst = a.e.payload + a.e.seg_off[seg];
+    const uint32_t nfull = (uint32_t)(n / kChunk);
+    const uint32_t rem = (uint32_t)(n % kChunk);
+    uint64_t words = 0, bits = 0;
+    if (nfull) {
+        u32x4 v[kWin];
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
+        uint32_t *__restrict__ out = dst;  // next unflushed word (always 256-byte aligned)
+        uint32_t pend = 0;                 // words waiting in LDS behind `out`
+        for (uint32_t c = 0; c < nfull; ++c) {
+            uint32_t w, b;
+            encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, stage, img,
+                                           out, pend, lane, w, b);
+            words += w;
+            bits += b;
+        }
+        if (ABL < 1 && (uint32_t)lane < pend) out[lane] = img[lane];  // segment tail
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (rem) {
+        uint32_t w, b;
+        encode_chunk<3, false>(src + (size_t)nfull * kChunk, rem, lut1, stage, img, dst + words, lane, w, b);
+        words += w;
+        bits += b;
+    }
+    if (lane == 0) {
+        a.e.seg_words[seg] = words;
+        atomicAdd(&a.e.ch_bits[ch], (unsigned long long)bits);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------
+struct Dtab2Args {
+    const uint8_t *peak, *enc, *sclv;
+    const uint32_t *codes;
+    uint32_t C, S, mode, W;
+    uint2 *dtab2;  // C << W entries {symbol bytes, n | bits << 8}
+};
+
+__global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
+{
+    const uint32_t ch = blockIdx.x;
+    const int S = (int)a.S, W = (int)a.W;
+    const int p = a.peak[ch];
+    const uint32_t k = a.enc[ch];
+    __shared__ uint32_t code[16], clen[16], sym[16];
+    if (threadIdx.x < (uint32_t)S) {
+        const uint32_t c = a.codes[k * 16 + threadIdx.x];
+        code[threadIdx.x] = c & 0xFFFFu;
+        clen[threadIdx.x] = c >> 16;
+        sym[threadIdx.x] = (uint32_t)symbol_of_rank((int)a.mode, S, p, (int)threadIdx.x);
+    }
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < (1u << W); idx += 256) {
+        uint32_t pos = 0, n = 0, bytes = 0;
+        for (int j = 0; j < 4; ++j) {
+            int hit = -1;
+            for (int r = 0; r < S; ++r) {
+                const uint32_t l = clen[r];
+                if (pos + l <= (uint32_t)W && ((idx >> pos) & ((1u << l) - 1u)) == code[r]) hit = r;
+            }
+            if (hit < 0) break;
+            bytes |= sym[hit] << (8 * n);
+            ++n;
+            pos += clen[hit];
+        }
+        a.dtab2[((size_t)ch << W) + idx] = make_uint2(bytes, n | (pos << 8));
+    }
+}
+
+struct Dec2Args {
+    DecArgs d;
+    TaskArgs t;
+    const uint2 *dtab2;
+    uint32_t W;         // table index bits
+    uint32_t stage_cap; // LDS words per wave for the staged chunk payload
+};
+
+__host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W) { return (2u << W) + kDtab / 4; }
+
+// Per-chunk pipeline state: the scanned header of the chunk about to be decoded.
+struct ChunkHdr {
+    uint32_t P;   // this lane's sub-stream starts at bit P of the chunk payload
+    uint32_t nw;  // payload words of the chunk
+};
+
+__device__ __forceinline__ ChunkHdr scan_header(uint32_t hw, int lane)
+{
+    const uint32_t len = (hw >> (16 * (lane & 1))) & 0xFFFFu;
+    const uint32_t incl = wave_scan_incl(len, lane);
+    ChunkHdr h;
+    h.P = incl - len;
+    h.nw = (__shfl(incl, 63, 64) + 31) >> 5;
+    return h;
+}
+
+// FAST: every lookup yields exactly 4 symbols (W >= 4 * maxlen).  Decodes one full chunk whose
+// whole payload (+3 words of read-ahead) already sits in LDS `stage`: the symbol loop issues no
+// global load, so nothing in it ever waits on the vector-memory counter (which also counts the
+// 16-byte output stores).
+template <bool FAST>
+__device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint2 *tab, uint32_t maskW,
+                                                    const uint32_t *stage, uint8_t *__restrict__ out,
+                                                    int lane)
+{
+#define MH_WORD(i) (stage[(i)])
+    uint32_t wi = h.P >> 5, bp = h.P & 31;
+    uint64_t buf = (uint64_t)MH_WORD(wi) | ((uint64_t)MH_WORD(wi + 1) << 32);
+    uint32_t nxt = MH_WORD(wi + 2);
+#define MH_REFILL()                                  \
+    if (bp >= 32) {                                  \
+        buf = (buf >> 32) | ((uint64_t)nxt << 32);   \
+        bp -= 32;                                    \
+        ++wi;                                        \
+        nxt = MH_WORD(wi + 2);                       \
+    }
+    uint64_t obuf = 0;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (FAST) {
+                const uint2 e = tab[(uint32_t)(buf >> bp) & maskW];
+                o[d] = e.x;
+                bp += e.y >> 8;
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (cnt < 4) {
+                        MH_REFILL();
+                        const uint2 e = tab[(uint32_t)(buf >> bp) & maskW];
+                        obuf |= (uint64_t)e.x << (8 * cnt);
+                        cnt += e.y & 0xFFu;
+                        bp += e.y >> 8;
+                    }
+                }
+                o[d] = (uint32_t)obuf;
+                obuf >>= 32;
+                cnt -= 4;
+            }
+        }
+        if (FAST) { MH_REFILL(); }
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + ((uint32_t)k * kLanes + lane) * MH_PIECE));
+    }
+#undef MH_REFILL
+#undef MH_WORD
+}
+
+// NR payload registers per lane: the next chunk's payload (up to NR*64 words) is fetched into
+// registers while the current chunk decodes, and lands in LDS at the top of the next iteration.
+// All those loads are issued BEFORE the current chunk's 16 output stores, so waiting for them
+// (in-order vmcnt) never waits for a store.
+template <bool FAST, int NR>
+__global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x;
+    const uint32_t seg0 = a.t.task_seg0[task];
+    const uint32_t nseg = a.t.task_n[task];
+    const uint32_t ch = a.d.seg_ch[seg0];
+    const uint32_t W = a.W;
+    uint2 *tab = reinterpret_cast<uint2 *>(smem);
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (2u << W));
+    {
+        const uint2 *g = a.dtab2 + ((size_t)ch << W);
+        for (uint32_t i = threadIdx.x; i < (1u << W); i += 256) tab[i] = g[i];
+        if (threadIdx.x < kDtab / 8)
+            reinterpret_cast<uint2 *>(tab1)[threadIdx.x] =
+                reinterpret_cast<const uint2 *>(a.d.dtab + (size_t)ch * kDtab)[threadIdx.x];
+    }
+    __syncthreads();
+    if ((uint32_t)wave >= nseg) return;
+    const uint32_t seg = seg0 + wave;
+    uint32_t *stage = smem + dec2_shared_dwords(W) + (size_t)wave * a.stage_cap;
+    const uint32_t maskW = (1u << W) - 1u;
+    const uint32_t *in = a.d.payload + a.d.seg_off[seg];
+    uint8_t *out = a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg];
+    const uint64_t n = a.d.seg_n[seg];
+    const uint32_t nfull = (uint32_t)(n / kChunk);
+    const uint32_t rem = (uint32_t)(n % kChunk);
+    if (nfull) {
+        uint32_t R[NR];
+        ChunkHdr cur = scan_header(in[lane >> 1], lane);
+        const uint32_t *pay = in + kHdrWords;
+        uint32_t ns = cur.nw + 3 < (uint32_t)(NR * 64) ? cur.nw + 3 : (uint32_t)(NR * 64);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];  // reads <= 3 words of slack
+        uint32_t hw_next = 0;
+        if (nfull > 1) hw_next = pay[cur.nw + (lane >> 1)];
+        for (uint32_t c = 0; c < nfull; ++c) {
+            // payload(c): registers -> LDS
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
+            const ChunkHdr hc = cur;
+            // rare: a chunk larger than the register prefetch -> copy the rest synchronously
+            for (uint32_t i = NR * 64 + lane; i < hc.nw + 3; i += 64) stage[i] = pay[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
+                pay = pay + cur.nw + kHdrWords;
+                cur = scan_header(hw_next, lane);
+                ns = cur.nw + 3 < (uint32_t)(NR * 64) ? cur.nw + 3 : (uint32_t)(NR * 64);
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];
+                if (c + 2 < nfull) hw_next = pay[cur.nw + (lane >> 1)];
+            }
+            decode_staged_chunk<FAST>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        in = pay + cur.nw;  // first word after the last full chunk
+    }
+    if (rem) {
+        const int L = a.d.dlen[ch];
+        decode_chunk<3, false>(in, rem, tab1, (1u << L) - 1u, out + (size_t)nfull * kChunk, lane);
+    }
+}
+
+}  // namespace mh

@@ -9,7 +9,7 @@
 #include <new>
 #include <vector>
 
-#include "mh_kernels.hpp"
+#include "mh_codec2.hpp"
 #include "muahuff.h"
 
 namespace {
@@ -100,6 +100,12 @@ struct mh_plan {
     unsigned long long *d_hist = nullptr;
     uint8_t *d_peak = nullptr, *d_enc = nullptr, *d_dtab = nullptr, *d_dlen = nullptr;
     uint2 *d_lut = nullptr;
+    // workgroup tasks: up to 4 consecutive segments of one channel
+    uint32_t *d_task_seg0 = nullptr;
+    uint8_t *d_task_n = nullptr;
+    uint32_t n_tasks = 0;
+    uint32_t W = 0;  // decode table index bits
+    uint2 *d_dtab2 = nullptr;
 };
 
 static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
@@ -132,14 +138,30 @@ static void launch_hist(const mh::HistArgs &a, uint64_t n_tiles, hipStream_t st)
     hipLaunchKernelGGL(mh::k_hist<NS>, dim3((unsigned)n_tiles), dim3(256), 0, st, a);
 }
 
-template <int FI>
-static int launch_encode(const mh::EncArgs &a, uint32_t waves, hipStream_t st)
+int g_ablate = 0;  // debug only (mhdbg_set_ablation); 0 in production
+
+template <int LC, int PB, int ABL = 0>
+static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 {
-    const size_t lds = (size_t)waves * mh::enc_wave_dwords(a.stage_dw) * sizeof(uint32_t);
+    const size_t lds = ((size_t)mh::kEncSharedDw + 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw)) * sizeof(uint32_t);
+    auto kern = mh::k_encode2<LC, PB, ABL>;
     if (lds > 64 * 1024)
-        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mh::k_encode<FI>),
+        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mh::k_encode<FI>, dim3((a.nseg + waves - 1) / waves), dim3(waves * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+template <bool FAST, int NR>
+static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
+{
+    const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W) + 4 * (size_t)a.stage_cap) * sizeof(uint32_t);
+    auto kern = mh::k_decode2<FAST, NR>;
+    if (lds > 64 * 1024)
+        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }
@@ -147,6 +169,9 @@ static int launch_encode(const mh::EncArgs &a, uint32_t waves, hipStream_t st)
 extern "C" {
 
 int mh_version(void) { return MH_VERSION; }
+
+/* debug hook, not part of the public ABI: selects a timing-only ablation of k_encode2 */
+void mhdbg_set_ablation(int level) { g_ablate = level; }
 
 const char *mh_last_error(void) { return g_err; }
 
@@ -195,7 +220,7 @@ int mh_plan_destroy(mh_plan *p)
     void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
-                    p->d_dlen, p->d_lut};
+                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_dtab2};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -238,21 +263,27 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
     // segments: seg_chunks chunks each, slot sized for the longest code of any encoder
     const uint64_t seg_samples = (uint64_t)I.seg_chunks * MH_CHUNK, L = I.maxlen;
     uint64_t slot = 0;
-    std::vector<uint32_t> tile_ch, tile_n;
+    std::vector<uint32_t> tile_ch, tile_n, task_seg0;
+    std::vector<uint8_t> task_n;
     std::vector<uint64_t> tile_start;
     for (uint32_t c = 0; c < C; ++c) {
         const uint64_t n = w1[c] - w0[c];
+        const size_t seg_begin = p->seg_ch.size();
         for (uint64_t first = 0; first < n; first += seg_samples) {
             const uint64_t m = n - first < seg_samples ? n - first : seg_samples;
             const uint64_t full = m / MH_CHUNK, rem = m % MH_CHUNK;
             uint64_t words = (full + (rem ? 1 : 0)) * MH_HDR_WORDS + full * ((MH_CHUNK * L + 31) / 32);
             if (rem) words += (rem * L + 31) / 32;
-            words = (words + 3) & ~(uint64_t)3;
+            words = (words + 31) & ~(uint64_t)31;  // slots start on 128-byte lines
             p->seg_ch.push_back(c);
             p->seg_first.push_back(first);
             p->seg_n.push_back(m);
             p->seg_off.push_back(slot);
             slot += words;
+        }
+        for (size_t s0 = seg_begin; s0 < p->seg_ch.size(); s0 += 4) {
+            task_seg0.push_back((uint32_t)s0);
+            task_n.push_back((uint8_t)(p->seg_ch.size() - s0 < 4 ? p->seg_ch.size() - s0 : 4));
         }
         for (uint64_t first = 0; first < n; first += kHistTile) {
             tile_ch.push_back(c);
@@ -263,6 +294,8 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
     p->info.n_segments = p->seg_ch.size();
     p->info.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
     p->n_tiles = tile_ch.size();
+    p->n_tasks = (uint32_t)task_seg0.size();
+    p->W = I.maxlen <= 2 ? 4 * I.maxlen : 11;
     // codebooks by rank: bit-reversed code (first code bit at bit 0) | len << 16
     std::vector<uint32_t> codes((size_t)K * 16, 0);
     for (uint32_t k = 0; k < K; ++k) {
@@ -283,7 +316,9 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
         (rc = upload(&p->d_tile_start, tile_start)) ||
         (rc = alloc(&p->d_hist, (size_t)C * mh::kHistStride)) || (rc = alloc(&p->d_peak, C)) ||
         (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_dtab, (size_t)C * mh::kDtab)) ||
-        (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)))
+        (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
+        (rc = upload(&p->d_task_seg0, task_seg0)) || (rc = upload(&p->d_task_n, task_n)) ||
+        (rc = alloc(&p->d_dtab2, (size_t)C << p->W)))
         return rc;
     return MH_OK;
 }
@@ -435,16 +470,25 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
     a.ch_bits = reinterpret_cast<unsigned long long *>(ch_bits);
     a.nseg = (uint32_t)p->info.n_segments;
     a.stage_dw = 8 * p->info.maxlen;
-    // waves per workgroup: as many as fit 160 KiB of LDS, at most 4
-    const size_t per_wave = (size_t)mh::enc_wave_dwords(a.stage_dw) * sizeof(uint32_t);
-    uint32_t waves = (uint32_t)((160 * 1024) / per_wave);
-    waves = waves > 4 ? 4 : (waves < 1 ? 1 : waves);
-    switch (flush_interval(p->info.maxlen)) {
-    case 16: return launch_encode<16>(a, waves, st);
-    case 8: return launch_encode<8>(a, waves, st);
-    case 4: return launch_encode<4>(a, waves, st);
-    default: return launch_encode<3>(a, waves, st);
+    mh::Enc2Args a2;
+    a2.e = a;
+    a2.t.task_seg0 = p->d_task_seg0;
+    a2.t.task_n = p->d_task_n;
+    a2.t.ntask = p->n_tasks;
+    const uint32_t L = p->info.maxlen;
+    const bool pb3 = p->info.S <= 8;  // 3-bit pair packing when every symbol fits 3 bits
+    if (L <= 2 && pb3 && g_ablate) {  // debug ablations of the S<=3 kernel
+        switch (g_ablate) {
+        case 1: return launch_encode2<0, 3, 1>(a2, st);
+        case 2: return launch_encode2<0, 3, 2>(a2, st);
+        case 3: return launch_encode2<0, 3, 3>(a2, st);
+        default: return launch_encode2<0, 3, 4>(a2, st);
+        }
     }
+    if (L <= 2) return pb3 ? launch_encode2<0, 3>(a2, st) : launch_encode2<0, 4>(a2, st);
+    if (L <= 4) return pb3 ? launch_encode2<1, 3>(a2, st) : launch_encode2<1, 4>(a2, st);
+    if (L <= 8) return pb3 ? launch_encode2<2, 3>(a2, st) : launch_encode2<2, 4>(a2, st);
+    return launch_encode2<3, 4>(a2, st);
 }
 
 int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, const uint8_t *peak,
@@ -477,15 +521,28 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
     a.dlen = p->d_dlen;
     a.out = out;
     a.nseg = (uint32_t)p->info.n_segments;
-    const dim3 grid((a.nseg + 3) / 4), block(256);
-    switch (flush_interval(p->info.maxlen)) {
-    case 16: hipLaunchKernelGGL(mh::k_decode<16>, grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(mh::k_decode<8>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(mh::k_decode<4>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(mh::k_decode<3>, grid, block, 0, st, a); break;
-    }
+    mh::Dtab2Args t2;
+    t2.peak = peak;
+    t2.enc = enc;
+    t2.sclv = p->d_sclv;
+    t2.codes = p->d_codes;
+    t2.C = p->info.C;
+    t2.S = p->info.S;
+    t2.mode = p->info.mode;
+    t2.W = p->W;
+    t2.dtab2 = p->d_dtab2;
+    hipLaunchKernelGGL(mh::k_build_dtab2, dim3(t2.C), dim3(256), 0, st, t2);
     MH_HIP(hipGetLastError());
-    return MH_OK;
+    mh::Dec2Args a2;
+    a2.d = a;
+    a2.t.task_seg0 = p->d_task_seg0;
+    a2.t.task_n = p->d_task_n;
+    a2.t.ntask = p->n_tasks;
+    a2.dtab2 = p->d_dtab2;
+    a2.W = p->W;
+    a2.stage_cap = (512 * p->info.maxlen + 4 + 63) & ~63u;  // worst-case chunk payload + read-ahead
+    // FAST (S <= 3): worst-case chunk payload 1024 words + 3 of slack -> 17 registers per lane
+    return p->info.maxlen <= 2 ? launch_decode2<true, 17>(a2, st) : launch_decode2<false, 32>(a2, st);
 }
 
 int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, uint32_t *dense,

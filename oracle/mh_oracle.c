@@ -265,7 +265,7 @@ uint64_t mho_slot_words(uint64_t n, uint32_t maxlen)
     uint64_t w = (full + (rem ? 1 : 0)) * MHO_HDR_WORDS;
     w += full * (((uint64_t)MHO_CHUNK * maxlen + 31) / 32);
     if (rem) w += (rem * maxlen + 31) / 32;
-    return (w + 3) & ~(uint64_t)3;
+    return (w + 31) & ~(uint64_t)31; /* slots start on 128-byte lines */
 }
 
 static void window_of(uint64_t T, const mho_params *p, uint64_t *w0, uint64_t *w1, int *skipped)

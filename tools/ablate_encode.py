@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Timing-only ablations of k_encode2 (S=3 kernel): which phase costs what.  Debug tool."""
+import ctypes as ct
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import muahuff
+from muahuff import codec, sclv, synth
+
+C, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 10_000_000
+cs = synth.generate(C, T, seed=0)
+plan = codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(3),
+                  seg_chunks=int(os.environ.get("SEG_CHUNKS", "8")))
+enc = plan.alloc_encoded()
+lib = muahuff._lib.lib()
+names = {0: "full", 1: "no global stores", 2: "+ no scan/merge", 3: "+ no staging writes", 4: "loads only"}
+for rounds in range(2):
+    for lvl in (0, 1, 2, 3, 4):
+        lib.mhdbg_set_ablation(lvl)
+        plan.encode(cs.data, out=enc)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            plan.encode(cs.data, out=enc)
+        b.record()
+        torch.cuda.synchronize()
+        print("round %d  ABL=%d %-22s %.3f ms" % (rounds, lvl, names[lvl], a.elapsed_time(b) / 5), flush=True)
+lib.mhdbg_set_ablation(0)
