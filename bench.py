@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--S", type=int, default=3)
     ap.add_argument("--hist-bits", type=int, default=6)
     ap.add_argument("--mode", type=int, default=1, help="1 approx-sort mapper, 0 no-sort")
-    ap.add_argument("--seg-chunks", type=int, default=8)
+    ap.add_argument("--seg-chunks", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-channels", type=int, default=16)

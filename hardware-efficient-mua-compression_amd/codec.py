@@ -56,7 +56,7 @@ class Plan:
     """One design point (S, h, mapper, window rule, K candidate encoders) over one channel
     layout.  Mirrors mh_plan_* of include/muahuff.h."""
 
-    def __init__(self, ch_off, ch_len, S, h, mode, window, sclv, seg_chunks=8):
+    def __init__(self, ch_off, ch_len, S, h, mode, window, sclv, seg_chunks=2):
         _need_gpu()
         self.ch_off = np.ascontiguousarray(ch_off, dtype=np.uint64)
         self.ch_len = np.ascontiguousarray(ch_len, dtype=np.uint64)

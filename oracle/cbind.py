@@ -62,7 +62,7 @@ def _p(a):
 class Params:
     """S, h, mode, window, sclv[K,S] (uint8), seg_chunks."""
 
-    def __init__(self, S, h, mode, window, sclv, seg_chunks=8):
+    def __init__(self, S, h, mode, window, sclv, seg_chunks=2):
         self.sclv = np.ascontiguousarray(np.asarray(sclv, dtype=np.uint8).reshape(-1, S))
         self.S, self.h, self.mode, self.window = int(S), int(h), int(mode), int(window)
         self.K = self.sclv.shape[0]

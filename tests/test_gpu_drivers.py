@@ -1,0 +1,62 @@
+"""The three driver ports against the outputs of the reference scripts themselves (golden
+fixture made by oracle/make_golden.py): bit-exact float64, NaNs included."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _tree(tmp_path, z):
+    root = tmp_path / "root"
+    fmt, res_a, res_n = tmp_path / "Formatted", tmp_path / "res_approx", tmp_path / "res_nosort"
+    for d in (root, fmt):
+        d.mkdir()
+    (root / "directories.txt").write_text(
+        "%% test tree\nFormatted_data_path = '%s'\nSCLV_path = '%s'\nBR_no_sort_results = '%s'\n"
+        "BR_approx_sort_results = '%s'\n" % (fmt, tmp_path / "no_such_dir", res_n, res_a))
+    for which in ("train", "test"):
+        data, bin_vector = helpers.unpack_dataset(z, which)
+        names = ["Flint", "Sabes", "Brochier"][:len(data[0])]
+        with open(fmt / ("all_binned_data_%s.pkl" % which), "wb") as f:
+            pickle.dump({"all_binned_data": data, "bin_vector": bin_vector, "datasets": names}, f)
+    return str(root), str(res_a), str(res_n)
+
+
+@pytest.mark.parametrize("tag", ["approx", "nosort"])
+def test_sweep_driver_is_bit_exact(tmp_path, tag):
+    import muahuff
+    from muahuff.drivers import get_BR_no_sort, get_BR_with_approx_sort
+    z, params = helpers.sweep()
+    root, res_a, res_n = _tree(tmp_path, z)
+    mod = get_BR_with_approx_sort if tag == "approx" else get_BR_no_sort
+    np.random.seed(params["seed"])
+    out = mod.run(root, nb_CV_iterations=params["nb_CV_iterations"],
+                  how_many_channels_Sabes=params["how_many_channels_Sabes"], verbose=False)
+    assert len(out) == 9 * 2 * (params["nb_CV_iterations"] - 1)
+    for (S, BP, cv), res in out.items():
+        key = "%s/S%d_BP%d_CV%d/" % (tag, S, BP, cv)
+        assert helpers.same_float(np.array(res["stored_all_var_BRs"], dtype=np.float64), z[key + "BRs"]), key
+        assert np.array_equal(np.concatenate([np.asarray(a, dtype=np.float64) for a in res["stored_SCLVs"]]),
+                              z[key + "SCLVs"]), key
+        assert np.array_equal(np.concatenate(res["stored_hist_SCLVs"]), z[key + "hist_SCLVs"]), key
+        assert helpers.same_float(res["stored_val_BR_data_proportion"], z[key + "proportion"]), key
+        # the pickle on disk has the reference's structure
+        fn = os.path.join(res_a if tag == "approx" else res_n, "BRs_S_%d_BP_%d_CV_%d.pkl" % (S, BP, cv))
+        with open(fn, "rb") as f:
+            r = pickle.load(f)
+        assert set(r) == {"stored_all_var_BRs", "stored_SCLVs", "stored_hist_SCLVs", "stored_val_BR_data_proportion"}
+        assert r["stored_SCLVs"][0].dtype == object and r["stored_hist_SCLVs"][0].dtype == np.int64
+        assert isinstance(r["stored_all_var_BRs"][0][0][0], np.float64)
+
+
+def test_chosen_system_driver(tmp_path):
+    from muahuff.drivers import test_chosen_system as tcs
+    z, _ = helpers.sweep()
+    root, _, _ = _tree(tmp_path, z)
+    got = tcs.run(root, "test", verbose=False)
+    assert helpers.same_float(got, helpers.chosen_system())

@@ -104,6 +104,27 @@ __global__ __launch_bounds__(256) void k_wave_rw(const uint8_t* __restrict__ src
     }
 }
 
+// decoder-like mix: each wave reads RIN bytes per chunk (contiguous per segment) and writes 16 KiB
+template <int ST>
+__global__ __launch_bounds__(256) void k_wave_wr(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t chunks, uint32_t rin, size_t nseg, size_t slot)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t seg = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const uint8_t* p = src + seg * slot;
+    uint8_t* o = dst + seg * (size_t)chunks * 16384;
+    u32x4 acc = {1,2,3,4};
+    for (uint32_t c = 0; c < chunks; ++c) {
+        if (rin) for (uint32_t i = lane * 16; i < rin; i += 1024) acc ^= __builtin_nontemporal_load((const u32x4*)(p + i));
+        p += rin;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            u32x4* q = (u32x4*)(o + (size_t)c*16384 + (k*64+lane)*16);
+            if (ST == 1) __builtin_nontemporal_store(acc, q); else *q = acc;
+        }
+    }
+}
+
 template <typename F> float timeit(F f, int reps = 5)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -139,6 +160,16 @@ int main()
             printf("wave_rw nt      wout=%4u : %.3f ms  read %.2f TB/s + write %.2f TB/s\n", wout, ms, bytes/ms/1e9, nseg*(double)chunks*wout/ms/1e9);
             ms = timeit([&]{ hipLaunchKernelGGL(k_wave_rw<2>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, wout, nseg, slot); });
             printf("wave_rw batch4  wout=%4u : %.3f ms  read %.2f TB/s + write %.2f TB/s\n", wout, ms, bytes/ms/1e9, nseg*(double)chunks*wout/ms/1e9);
+        }
+    }
+    {
+        const uint32_t chunks = 8; const size_t nseg = bytes / ((size_t)chunks * 16384);
+        for (uint32_t rin : {0u, 2816u}) {
+            const size_t slot = (size_t)chunks * 4224;
+            float ms = timeit([&]{ hipLaunchKernelGGL(k_wave_wr<0>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, rin, nseg, slot); });
+            printf("wave_wr plain   rin=%4u : %.3f ms  write %.2f TB/s\n", rin, ms, bytes/ms/1e9);
+            ms = timeit([&]{ hipLaunchKernelGGL(k_wave_wr<1>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, rin, nseg, slot); });
+            printf("wave_wr nt      rin=%4u : %.3f ms  write %.2f TB/s\n", rin, ms, bytes/ms/1e9);
         }
     }
     for (int g : {2048, 8192}) {
