@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--seg-chunks", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-channels", type=int, default=16)
+    ap.add_argument("--cpu-sample-channels", type=int, default=96)
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--verify", action="store_true", help="round-trip check after the timed region")
     return ap.parse_args()
@@ -80,6 +80,22 @@ def cpu_baseline(cs_host, ch_off, ch_len, S, h, mode, tab, seg_chunks, n_ch):
     t_np = time.perf_counter() - t0
     res["numpy_measure_msamples_s"] = (st["e"] - st["c"]) / t_np / 1e6
     return samples, res
+
+
+def pmc_traffic(kernel, C, T, S, h, seg_chunks):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE cannot be collected while timing; they come from separate --pmc runs of this
+    same command, profiles/r01_pmc_traffic.json).  None when the workload differs."""
+    fn = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(fn) as f:
+            d = json.load(f)
+        w = d["workload"]
+        if (w["channels_per_gpu"], w["bins"], w["S"], w["hist_bits"], w["seg_chunks"]) != (C, T, S, h, seg_chunks):
+            return None, None
+        return d["kernels"][kernel]["hbm_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, gfx950 FETCH x2)"
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
@@ -170,10 +186,11 @@ def main():
         value = total_samples * a.steps / dt / 1e6
         # dominant kernel = the slower of the two ops of a step
         if enc_ms >= dec_ms:
-            kname, kms, abytes = "k_encode", enc_ms, samples * (1.0 + b / 8.0)
+            kname, kms, abytes = "k_encode2", enc_ms, samples * (1.0 + b / 8.0)
         else:
-            kname, kms, abytes = "k_decode", dec_ms, samples * (b / 8.0 + 1.0)
+            kname, kms, abytes = "k_decode2", dec_ms, samples * (b / 8.0 + 1.0)
         achieved = abytes / (kms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(kname, C, T, S, h, a.seg_chunks)
         info = muahuff.device_info(local)
         line = {
             "metric": "MSamples/s encode+decode (static-Huffman MUA codec)",
@@ -189,7 +206,8 @@ def main():
             "kernels_ms": {"encode_op": enc_ms, "decode_op": dec_ms,
                            "encode_MSamples_s": samples / enc_ms / 1e3, "decode_MSamples_s": samples / dec_ms / 1e3},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes": abytes,
                          "algorithmic_bytes_per_sample": abytes / samples,
                          "timing": "HIP events on the launch stream around the op (calibrate+memset+kernel)"},
             "device": info["name"] + " " + info["arch"],
