@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-channels", type=int, default=96)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse "
+                    "the multi-rank control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="round-trip check after the timed region")
     return ap.parse_args()
 
@@ -105,12 +107,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1) if a.dist_backend == "gloo" else local
     torch.cuda.set_device(local)
     dist = None
+    coll_dev = "cuda" if a.dist_backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.dist_backend)
 
     import muahuff
     from muahuff import codec, sclv, synth
@@ -150,7 +158,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -167,7 +175,8 @@ def main():
         dense, tot = plan.compact(enc)
         barrier()
         g0 = time.perf_counter()
-        pay, offs = mdist.gather_payload(dense.payload, int(tot.item()), dst=0)
+        src = dense.payload if coll_dev == "cuda" else dense.payload.cpu()
+        pay, offs = mdist.gather_payload(src, int(tot.item()), dst=0)
         barrier()
         g = time.perf_counter() - g0
         gather = dict(ms=g * 1e3, bytes_total=int(offs[-1]) * 4,
