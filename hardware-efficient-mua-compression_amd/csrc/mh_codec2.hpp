@@ -39,6 +39,54 @@ __host__ __device__ inline uint32_t enc2_wave_dwords(uint32_t stage_dw)
     return stage_dw * 64 + 64 + 32 + stage_dw * 64;  // staging + (carried tail + chunk image)
 }
 
+// Slow path for a chunk (m <= 16384 samples) whose sub-streams do not fit the capped LDS staging
+// (more than 3 bits/sample in some lane): two passes straight from global memory -- lengths,
+// wave prefix sum, zero the chunk image in place, then OR every codeword into it with global
+// atomics.  Correct for any data; only adversarial inputs ever get here.
+// Returns {words written, code bits}.
+__device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src, uint32_t m,
+                                                const uint2 *lut1, uint32_t *__restrict__ gdst,
+                                                int lane)
+{
+    uint32_t tot = 0;
+#pragma unroll 1
+    for (int k = 0; k < kRows; ++k) {
+        const uint32_t base = ((uint32_t)k * kLanes + lane) * MH_PIECE;
+#pragma unroll 1
+        for (int i = 0; i < MH_PIECE; ++i)
+            if (base + i < m) {
+                const uint32_t b = src[base + i];
+                tot += lut1[b > 15u ? 15u : b].y;
+            }
+    }
+    const uint32_t incl = wave_scan_incl(tot, lane);
+    const uint32_t P = incl - tot;
+    const uint32_t B = __shfl(incl, 63, 64);
+    const uint32_t nw = (B + 31) >> 5;
+    const uint32_t other = __shfl_down(tot, 1, 64);
+    if (!(lane & 1)) gdst[lane >> 1] = tot | (other << 16);
+    uint32_t *gpay = gdst + kHdrWords;
+    for (uint32_t i = lane; i < nw; i += 64) gpay[i] = 0;
+    __threadfence();  // the zeros are at L2 before any atomic below
+    uint32_t pos = P;
+#pragma unroll 1
+    for (int k = 0; k < kRows; ++k) {
+        const uint32_t base = ((uint32_t)k * kLanes + lane) * MH_PIECE;
+#pragma unroll 1
+        for (int i = 0; i < MH_PIECE; ++i)
+            if (base + i < m) {
+                const uint32_t b = src[base + i];
+                const uint2 e = lut1[b > 15u ? 15u : b];
+                const uint64_t v = (uint64_t)e.x << (pos & 31);
+                atomicOr(&gpay[pos >> 5], (uint32_t)v);
+                if ((uint32_t)(v >> 32)) atomicOr(&gpay[(pos >> 5) + 1], (uint32_t)(v >> 32));
+                pos += e.y;
+            }
+    }
+    __threadfence();
+    return make_uint2(kHdrWords + nw, B);
+}
+
 // LC: 0 maxlen<=2 (flush check per piece), 1 maxlen<=4 (per 2 dwords), 2 maxlen<=8 (per dword),
 //     3 maxlen==9 (per pair, no 32-bit quad merge)
 // PB: bits per symbol in the pair index.  PB=3 (S<=8) keeps the hot entries (small symbols) on
@@ -79,20 +127,20 @@ __device__ __forceinline__ u32x4 load_row(const uint8_t *p)
 // writes, 4 loads only
 template <int LC, int PB, int ABL = 0>
 __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_t *__restrict__ cur,
-                                                  bool has_next, const uint2 *lut2, uint32_t *stage,
-                                                  uint32_t *img, uint32_t *__restrict__ &dst,
-                                                  uint32_t &pend, int lane, uint32_t &words,
-                                                  uint32_t &bits)
+                                                  bool has_next, const uint2 *lut2, const uint2 *lut1,
+                                                  uint32_t *stage, uint32_t cap, uint32_t *img,
+                                                  uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
+                                                  uint32_t &words, uint32_t &bits)
 {
     uint64_t acc = 0;
     uint32_t nb = 0, sp = 0;
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
-#define MH_FLUSH()                                            \
-    if (nb >= 32) {                                           \
-        if (ABL < 3) stage[sp * 64 + lane] = (uint32_t)acc;   \
-        acc >>= 32;                                           \
-        nb -= 32;                                             \
-        ++sp;                                                 \
+#define MH_FLUSH()                                                        \
+    if (nb >= 32) {                                                       \
+        if (ABL < 3 && sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;   \
+        acc >>= 32;                                                       \
+        nb -= 32;                                                         \
+        ++sp;                                                             \
     }
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
@@ -138,8 +186,20 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
     }
     const uint32_t tot = sp * 32 + nb;
     if (nb > 0) {
-        stage[sp * 64 + lane] = (uint32_t)acc;
+        if (sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;
         ++sp;
+    }
+    if (__any(sp > cap)) {  // some sub-stream outgrew the LDS staging: redo this chunk the slow way
+        if ((uint32_t)lane < pend) dst[lane] = img[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        dst += pend;
+        pend = 0;
+        const uint2 r = encode_chunk_slow(cur, kChunk, lut1, dst, lane);
+        words = r.x;
+        bits = r.y;
+        dst += words;
+        return;
     }
     const uint32_t incl = wave_scan_incl(tot, lane);
     const uint32_t P = incl - tot;
@@ -167,7 +227,7 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
     if (ABL < 1)
         for (uint32_t i = lane * 4; i < nflush; i += 256)
             __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(img + i),
-                                        reinterpret_cast<u32x4 *>(dst + i));
+                                        reinterpret_cast<u32x4_u *>(dst + i));
     const uint32_t tail = total - nflush;
     uint32_t t = 0;
     if ((uint32_t)lane < tail) t = img[nflush + lane];
@@ -224,8 +284,8 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
         uint32_t pend = 0;                 // words waiting in LDS behind `out`
         for (uint32_t c = 0; c < nfull; ++c) {
             uint32_t w, b;
-            encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, stage, img,
-                                           out, pend, lane, w, b);
+            encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, lut1, stage,
+                                           a.e.stage_dw, img, out, pend, lane, w, b);
             words += w;
             bits += b;
         }
@@ -235,7 +295,13 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     }
     if (rem) {
         uint32_t w, b;
-        encode_chunk<3, false>(src + (size_t)nfull * kChunk, rem, lut1, stage, img, dst + words, lane, w, b);
+        encode_chunk<3, false>(src + (size_t)nfull * kChunk, rem, lut1, stage, img + 64, dst + words, lane, w,
+                               b, a.e.stage_dw);
+        if (w == 0) {  // staging overflow in the partial chunk
+            const uint2 r = encode_chunk_slow(src + (size_t)nfull * kChunk, rem, lut1, dst + words, lane);
+            w = r.x;
+            b = r.y;
+        }
         words += w;
         bits += b;
     }
@@ -251,14 +317,16 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
 struct Dtab2Args {
     const uint8_t *peak, *enc, *sclv;
     const uint32_t *codes;
-    uint32_t C, S, mode, W;
-    uint2 *dtab2;  // C << W entries {symbol bytes, n | bits << 8}
+    uint32_t C, S, mode, W, K;
+    uint2 *dtab2;  // C << W entries {K symbol bytes, bits consumed}
 };
 
+// Entry idx = the next W stream bits; it decodes exactly K symbols (W >= K * maxlen, and the
+// code is complete, so K codewords always fit) -> {symbols spread to bytes, total length}.
 __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
 {
     const uint32_t ch = blockIdx.x;
-    const int S = (int)a.S, W = (int)a.W;
+    const int S = (int)a.S, W = (int)a.W, K = (int)a.K;
     const int p = a.peak[ch];
     const uint32_t k = a.enc[ch];
     __shared__ uint32_t code[16], clen[16], sym[16];
@@ -270,19 +338,17 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
     }
     __syncthreads();
     for (uint32_t idx = threadIdx.x; idx < (1u << W); idx += 256) {
-        uint32_t pos = 0, n = 0, bytes = 0;
-        for (int j = 0; j < 4; ++j) {
-            int hit = -1;
+        uint32_t pos = 0, bytes = 0;
+        for (int j = 0; j < K; ++j) {
+            int hit = 0;
             for (int r = 0; r < S; ++r) {
                 const uint32_t l = clen[r];
-                if (pos + l <= (uint32_t)W && ((idx >> pos) & ((1u << l) - 1u)) == code[r]) hit = r;
+                if (((idx >> pos) & ((1u << l) - 1u)) == code[r]) hit = r;
             }
-            if (hit < 0) break;
-            bytes |= sym[hit] << (8 * n);
-            ++n;
+            bytes |= sym[hit] << (8 * j);
             pos += clen[hit];
         }
-        a.dtab2[((size_t)ch << W) + idx] = make_uint2(bytes, n | (pos << 8));
+        a.dtab2[((size_t)ch << W) + idx] = make_uint2(bytes, pos);
     }
 }
 
@@ -290,8 +356,7 @@ struct Dec2Args {
     DecArgs d;
     TaskArgs t;
     const uint2 *dtab2;
-    uint32_t W;         // table index bits
-    uint32_t stage_cap; // LDS words per wave for the staged chunk payload
+    uint32_t W;  // table index bits
 };
 
 __host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W) { return (2u << W) + kDtab / 4; }
@@ -312,65 +377,52 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw, int lane)
     return h;
 }
 
-// FAST: every lookup yields exactly 4 symbols (W >= 4 * maxlen).  Decodes one full chunk whose
-// whole payload (+3 words of read-ahead) already sits in LDS `stage`: the symbol loop issues no
-// global load, so nothing in it ever waits on the vector-memory counter (which also counts the
-// 16-byte output stores).
-template <bool FAST>
+// Decodes one full chunk whose whole payload (+3 words of read-ahead) sits in LDS `stage`.
+// K symbols per table lookup (4, 2 or 1), bit buffer topped up every M lookups (M * W <= 33).
+// The loop issues no global load, so nothing in it waits on the vector-memory counter (which
+// also counts the 16-byte output stores).
+template <int K, int M>
 __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint2 *tab, uint32_t maskW,
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
                                                     int lane)
 {
-#define MH_WORD(i) (stage[(i)])
     uint32_t wi = h.P >> 5, bp = h.P & 31;
-    uint64_t buf = (uint64_t)MH_WORD(wi) | ((uint64_t)MH_WORD(wi + 1) << 32);
-    uint32_t nxt = MH_WORD(wi + 2);
+    uint64_t buf = (uint64_t)stage[wi] | ((uint64_t)stage[wi + 1] << 32);
+    uint32_t nxt = stage[wi + 2];
 #define MH_REFILL()                                  \
     if (bp >= 32) {                                  \
         buf = (buf >> 32) | ((uint64_t)nxt << 32);   \
         bp -= 32;                                    \
         ++wi;                                        \
-        nxt = MH_WORD(wi + 2);                       \
+        nxt = stage[wi + 2];                         \
     }
-    uint64_t obuf = 0;
-    uint32_t cnt = 0;
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         u32x4 o;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            if (FAST) {
-                const uint2 e = tab[(uint32_t)(buf >> bp) & maskW];
-                o[d] = e.x;
-                bp += e.y >> 8;
-            } else {
+            uint32_t w = 0;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    if (cnt < 4) {
-                        MH_REFILL();
-                        const uint2 e = tab[(uint32_t)(buf >> bp) & maskW];
-                        obuf |= (uint64_t)e.x << (8 * cnt);
-                        cnt += e.y & 0xFFu;
-                        bp += e.y >> 8;
-                    }
-                }
-                o[d] = (uint32_t)obuf;
-                obuf >>= 32;
-                cnt -= 4;
+            for (int i = 0; i < 4 / K; ++i) {
+                const uint2 e = tab[(uint32_t)(buf >> bp) & maskW];
+                w |= e.x << (8 * K * i);
+                bp += e.y;
+                if ((d * (4 / K) + i + 1) % M == 0) { MH_REFILL(); }
             }
+            o[d] = w;
         }
-        if (FAST) { MH_REFILL(); }
         __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + ((uint32_t)k * kLanes + lane) * MH_PIECE));
     }
 #undef MH_REFILL
-#undef MH_WORD
 }
 
 // NR payload registers per lane: the next chunk's payload (up to NR*64 words) is fetched into
 // registers while the current chunk decodes, and lands in LDS at the top of the next iteration.
 // All those loads are issued BEFORE the current chunk's 16 output stores, so waiting for them
-// (in-order vmcnt) never waits for a store.
-template <bool FAST, int NR>
+// (in-order vmcnt) never waits for a store.  A chunk whose payload exceeds NR*64 words (more
+// than 3 bits/sample when NR = 24; impossible when NR = 17 and maxlen <= 2) takes the
+// per-symbol routine that reads the stream straight from global memory.
+template <int K, int M, int NR>
 __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -392,8 +444,10 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
     __syncthreads();
     if ((uint32_t)wave >= nseg) return;
     const uint32_t seg = seg0 + wave;
-    uint32_t *stage = smem + dec2_shared_dwords(W) + (size_t)wave * a.stage_cap;
+    constexpr uint32_t kCap = NR * 64;
+    uint32_t *stage = smem + dec2_shared_dwords(W) + (size_t)wave * kCap;
     const uint32_t maskW = (1u << W) - 1u;
+    const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
     const uint32_t *in = a.d.payload + a.d.seg_off[seg];
     uint8_t *out = a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg];
     const uint64_t n = a.d.seg_n[seg];
@@ -403,41 +457,40 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
         uint32_t R[NR];
         ChunkHdr cur = scan_header(in[lane >> 1], lane);
         const uint32_t *pay = in + kHdrWords;
-        uint32_t ns = cur.nw + 3 < (uint32_t)(NR * 64) ? cur.nw + 3 : (uint32_t)(NR * 64);
+        uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
 #pragma unroll
         for (int j = 0; j < NR; ++j)
             if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];  // reads <= 3 words of slack
         uint32_t hw_next = 0;
         if (nfull > 1) hw_next = pay[cur.nw + (lane >> 1)];
         for (uint32_t c = 0; c < nfull; ++c) {
-            // payload(c): registers -> LDS
 #pragma unroll
-            for (int j = 0; j < NR; ++j)
+            for (int j = 0; j < NR; ++j)  // payload(c): registers -> LDS
                 if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
             const ChunkHdr hc = cur;
-            // rare: a chunk larger than the register prefetch -> copy the rest synchronously
-            for (uint32_t i = NR * 64 + lane; i < hc.nw + 3; i += 64) stage[i] = pay[i];
+            const uint32_t *pay_c = pay;
+            const bool staged = ns != 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
                 pay = pay + cur.nw + kHdrWords;
                 cur = scan_header(hw_next, lane);
-                ns = cur.nw + 3 < (uint32_t)(NR * 64) ? cur.nw + 3 : (uint32_t)(NR * 64);
+                ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
                     if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];
                 if (c + 2 < nfull) hw_next = pay[cur.nw + (lane >> 1)];
             }
-            decode_staged_chunk<FAST>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
+            if (staged)
+                decode_staged_chunk<K, M>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
+            else
+                decode_chunk<3, true>(pay_c - kHdrWords, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
         in = pay + cur.nw;  // first word after the last full chunk
     }
-    if (rem) {
-        const int L = a.d.dlen[ch];
-        decode_chunk<3, false>(in, rem, tab1, (1u << L) - 1u, out + (size_t)nfull * kChunk, lane);
-    }
+    if (rem) decode_chunk<3, false>(in, rem, tab1, mask1, out + (size_t)nfull * kChunk, lane);
 }
 
 }  // namespace mh

@@ -251,7 +251,8 @@ template <int FI, bool FULL>
 __device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ src, uint32_t m,
                                              const uint2 *lut, uint32_t *stage, uint32_t *img,
                                              uint32_t *__restrict__ dst, int lane,
-                                             uint32_t &words, uint32_t &bits)
+                                             uint32_t &words, uint32_t &bits,
+                                             uint32_t cap = 0xFFFFFFFFu)
 {
     u32x4 v[kRows];
     int cnt[kRows];
@@ -291,7 +292,7 @@ __device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ src, ui
             }
             if ((i + 1) % FI == 0 || i == MH_PIECE - 1) {
                 if (nb >= 32) {
-                    stage[sp * 64 + lane] = (uint32_t)acc;
+                    if (sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;
                     acc >>= 32;
                     nb -= 32;
                     ++sp;
@@ -301,8 +302,13 @@ __device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ src, ui
     }
     const uint32_t tot = sp * 32 + nb;  // exact code bits of this sub-stream
     if (nb > 0) {
-        stage[sp * 64 + lane] = (uint32_t)acc;
+        if (sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;
         ++sp;
+    }
+    if (__any(sp > cap)) {  // LDS staging too small for this chunk: the caller takes the slow path
+        words = 0;
+        bits = 0;
+        return;
     }
     // sub-stream placement: exclusive prefix over lanes
     const uint32_t incl = wave_scan_incl(tot, lane);

@@ -105,6 +105,7 @@ struct mh_plan {
     uint8_t *d_task_n = nullptr;
     uint32_t n_tasks = 0;
     uint32_t W = 0;  // decode table index bits
+    uint32_t dec_K = 4;  // symbols per decode-table lookup
     uint2 *d_dtab2 = nullptr;
 };
 
@@ -153,11 +154,11 @@ static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
     return MH_OK;
 }
 
-template <bool FAST, int NR>
+template <int K, int M, int NR>
 static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
 {
-    const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W) + 4 * (size_t)a.stage_cap) * sizeof(uint32_t);
-    auto kern = mh::k_decode2<FAST, NR>;
+    const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
+    auto kern = mh::k_decode2<K, M, NR>;
     if (lds > 64 * 1024)
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -295,7 +296,9 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
     p->info.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
     p->n_tiles = tile_ch.size();
     p->n_tasks = (uint32_t)task_seg0.size();
-    p->W = I.maxlen <= 2 ? 4 * I.maxlen : 11;
+    // decode table: K symbols per lookup, W = K * maxlen index bits (<= 12)
+    p->dec_K = I.maxlen <= 2 ? 4 : I.maxlen <= 6 ? 2 : 1;
+    p->W = p->dec_K * I.maxlen;
     // codebooks by rank: bit-reversed code (first code bit at bit 0) | len << 16
     std::vector<uint32_t> codes((size_t)K * 16, 0);
     for (uint32_t k = 0; k < K; ++k) {
@@ -469,7 +472,10 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
     a.seg_words = seg_words;
     a.ch_bits = reinterpret_cast<unsigned long long *>(ch_bits);
     a.nseg = (uint32_t)p->info.n_segments;
-    a.stage_dw = 8 * p->info.maxlen;
+    // lane-private LDS staging: worst case 8*maxlen dwords per lane, capped at 32 (= 4 bits per
+    // sample averaged over a 256-sample sub-stream; a clipped spike-count channel at S <= 10 stays
+    // well below that).  Chunks that outgrow it take the encoder's two-pass global slow path.
+    a.stage_dw = 8 * p->info.maxlen < 32 ? 8 * p->info.maxlen : 32;
     mh::Enc2Args a2;
     a2.e = a;
     a2.t.task_seg0 = p->d_task_seg0;
@@ -530,6 +536,7 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
     t2.S = p->info.S;
     t2.mode = p->info.mode;
     t2.W = p->W;
+    t2.K = p->dec_K;
     t2.dtab2 = p->d_dtab2;
     hipLaunchKernelGGL(mh::k_build_dtab2, dim3(t2.C), dim3(256), 0, st, t2);
     MH_HIP(hipGetLastError());
@@ -540,9 +547,11 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
     a2.t.ntask = p->n_tasks;
     a2.dtab2 = p->d_dtab2;
     a2.W = p->W;
-    a2.stage_cap = (512 * p->info.maxlen + 4 + 63) & ~63u;  // worst-case chunk payload + read-ahead
-    // FAST (S <= 3): worst-case chunk payload 1024 words + 3 of slack -> 17 registers per lane
-    return p->info.maxlen <= 2 ? launch_decode2<true, 17>(a2, st) : launch_decode2<false, 32>(a2, st);
+    const uint32_t L = p->info.maxlen;
+    if (L <= 2) return launch_decode2<4, 4, 17>(a2, st);  // worst-case chunk = 1027 words: never oversize
+    if (L == 3) return launch_decode2<2, 2, 25>(a2, st);  // worst case 1539 words: never oversize
+    if (L <= 6) return launch_decode2<2, 2, 32>(a2, st);  // staged up to 4 bits/sample
+    return launch_decode2<1, 2, 32>(a2, st);
 }
 
 int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, uint32_t *dense,

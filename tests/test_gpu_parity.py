@@ -177,6 +177,44 @@ def test_unaligned_buffer_and_many_encoders(mh):
     plan.close()
 
 
+@pytest.mark.parametrize("S,mode,gen,rows", [
+    (10, 1, "uniform", None), (7, 1, "uniform", None), (10, 0, "top", None),
+    (4, 0, "top", [[1, 2, 3, 3]]),                      # every sample 3 bits: exactly the maxlen-3 worst case
+    (10, 0, "top", [[1, 2, 3, 4, 5, 6, 7, 8, 9, 9]]),   # every sample 9 bits: far beyond any LDS cap
+    (6, 0, "uniform", [[1, 2, 3, 4, 5, 5]]),
+])
+def test_slow_paths_for_incompressible_data(mh, S, mode, gen, rows):
+    """Data that needs > 3 bits/sample overflows the capped LDS staging (encoder) and the staged
+    payload (decoder): both must fall back to their global-memory routines and stay exact."""
+    rng = np.random.RandomState(S * 7 + mode)
+    lens = [16384 * 3, 16384 + 5000, 70001, 16384, 100, 40000]
+    if gen == "uniform":
+        chans = [rng.randint(0, 13, size=T).astype(np.uint8) for T in lens]
+    else:
+        chans = [np.full(T, S - 1, np.uint8) for T in lens]
+        chans[2][::7] = 0
+    tab = helpers.sclv_tables()[S] if rows is None else np.array(rows, np.uint8)
+    cs = _cs(mh, chans)
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, 4, mode, mh.WIN_AFTER_CAL, tab, seg_chunks=2)
+    p = OC.Params(S, 4, mode, OC.WIN_AFTER_CAL, tab, seg_chunks=2)
+    host = cs.data.cpu().numpy()
+    e = plan.encode(cs.data)
+    oe = OC.encode(host, cs.ch_off, cs.ch_len, p)
+    sw = e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments]
+    assert np.array_equal(sw, oe["seg_words"])
+    assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+    pay = e.payload.cpu().numpy().view(np.uint32)
+    seg = plan.segments()
+    for s_ in range(plan.n_segments):
+        o, n = int(seg["off"][s_]), int(sw[s_])
+        assert np.array_equal(pay[o:o + n], oe["payload"][o:o + n]), "segment %d" % s_
+    out = torch.zeros_like(cs.data)
+    plan.decode(e, out)
+    want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host))
+    assert np.array_equal(out.cpu().numpy(), want)
+    plan.close()
+
+
 def test_empty_channel_raises_like_reference(mh):
     with pytest.raises(IndexError):
         mh.codec.Plan(np.zeros(2, np.uint64), np.array([10, 0], np.uint64), 3, 6, 1, 0,
