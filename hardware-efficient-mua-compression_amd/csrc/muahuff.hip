@@ -409,17 +409,15 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
         a.tile_start = p->d_tile_start;
         a.tile_n = p->d_tile_n;
         a.hist = p->d_hist;
-        switch (p->info.S - 1) {
-        case 1: launch_hist<1>(a, p->n_tiles, st); break;
-        case 2: launch_hist<2>(a, p->n_tiles, st); break;
-        case 3: launch_hist<3>(a, p->n_tiles, st); break;
-        case 4: launch_hist<4>(a, p->n_tiles, st); break;
-        case 5: launch_hist<5>(a, p->n_tiles, st); break;
-        case 6: launch_hist<6>(a, p->n_tiles, st); break;
-        case 7: launch_hist<7>(a, p->n_tiles, st); break;
-        case 8: launch_hist<8>(a, p->n_tiles, st); break;
-        default: launch_hist<9>(a, p->n_tiles, st); break;
-        }
+        const unsigned nt = (unsigned)p->n_tiles;
+        if (p->info.S == 2)
+            launch_hist<1>(a, p->n_tiles, st);  // byte-compare kernel: already at the read floor
+        else if (p->info.S == 3)
+            launch_hist<2>(a, p->n_tiles, st);
+        else if (p->info.S <= 8)  // pair-LUT histogram, 3-bit pair packing
+            hipLaunchKernelGGL(mh::k_hist2<3>, dim3(nt), dim3(256), 0, st, a, p->info.S);
+        else                      // S = 9, 10: 4-bit packing, xor-swizzled
+            hipLaunchKernelGGL(mh::k_hist2<4>, dim3(nt), dim3(256), 0, st, a, p->info.S);
         MH_HIP(hipGetLastError());
     }
     mh::FinArgs f;
