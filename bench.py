@@ -162,6 +162,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # auxiliary, outside the timed region: mh_measure on the same resident batch with the
+    # reference's own window rule [c, c+T/2) -- the only thing the reference itself computes
+    plan_m = codec.Plan(cs.ch_off, cs.ch_len, S, h, a.mode, muahuff.WIN_REF_HALF, tab)
+    meas = plan_m.measure(cs.data)
+    torch.cuda.synchronize()
+    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    m0.record()
+    for _ in range(3):
+        plan_m.measure(cs.data, out=meas)
+    m1.record()
+    torch.cuda.synchronize()
+    meas_ms = m0.elapsed_time(m1) / 3
+    meas_samples = plan_m.window_samples
+    ref_bits_per_sample = float(meas.bits.sum().item()) / max(meas_samples, 1)
+    plan_m.close()
+
     enc_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(a.steps)]))
     dec_ms = float(np.mean([ev[i][1].elapsed_time(ev[i][2]) for i in range(a.steps)]))
     bits = int(enc.ch_bits.sum().item())
@@ -213,7 +229,10 @@ def main():
                        "seg_chunks": a.seg_chunks, "parallelism": "channels sharded x%d, no data-path collective" % world},
             "bits_per_sample": {"payload": b, "container": cb},
             "kernels_ms": {"encode_op": enc_ms, "decode_op": dec_ms,
-                           "encode_MSamples_s": samples / enc_ms / 1e3, "decode_MSamples_s": samples / dec_ms / 1e3},
+                           "encode_MSamples_s": samples / enc_ms / 1e3, "decode_MSamples_s": samples / dec_ms / 1e3,
+                           "measure_op": meas_ms, "measure_MSamples_s": meas_samples / meas_ms / 1e3,
+                           "measure_GBps": meas_samples / meas_ms / 1e6,
+                           "measure_window": "[c, c+T/2) reference rule, bits/sample %.4f" % ref_bits_per_sample},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes": abytes,
