@@ -576,8 +576,25 @@ __global__ __launch_bounds__(256) void k_hist2(HistArgs a, uint32_t S)
     __syncthreads();
     if ((uint32_t)tid < S - 1) {  // the top bin is the window length minus the rest (k_finalize)
         const uint32_t v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-        if (v) atomicAdd(&a.hist[(size_t)ch * kHistStride + tid], (unsigned long long)v);
+        const uint32_t slot = a.tile_slot ? a.tile_slot[tile] : ch;
+        if (v) atomicAdd(&a.hist[(size_t)slot * kHistStride + tid], (unsigned long long)v);
     }
+}
+
+// [slot][16] u64 scratch (bins 0..8 counted) -> dense [slot][10], top bin = interval length - rest
+__global__ __launch_bounds__(256) void k_sweep_finalize(const unsigned long long *scratch,
+                                                        const uint64_t *slot_len, uint32_t nslots,
+                                                        uint64_t *out)
+{
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= nslots) return;
+    uint64_t rest = 0;
+    for (int b = 0; b < MH_SWEEP_BINS - 1; ++b) {
+        const uint64_t v = scratch[(size_t)s * kHistStride + b];
+        out[(size_t)s * MH_SWEEP_BINS + b] = v;
+        rest += v;
+    }
+    out[(size_t)s * MH_SWEEP_BINS + MH_SWEEP_BINS - 1] = slot_len[s] - rest;
 }
 
 }  // namespace mh

@@ -119,7 +119,8 @@ struct HistArgs {
     const uint32_t *tile_ch;
     const uint64_t *tile_start;  // relative to the channel start
     const uint32_t *tile_n;
-    unsigned long long *hist;    // C*16, zeroed before the launch
+    unsigned long long *hist;    // [slot][16], zeroed before the launch
+    const uint32_t *tile_slot;   // histogram slot of each tile; NULL = the tile's channel
 };
 
 template <int NS>
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a)
     __syncthreads();
     if (tid < NS) {
         const uint32_t v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-        if (v) atomicAdd(&a.hist[(size_t)ch * kHistStride + tid], (unsigned long long)v);
+        const uint32_t slot = a.tile_slot ? a.tile_slot[tile] : ch;
+        if (v) atomicAdd(&a.hist[(size_t)slot * kHistStride + tid], (unsigned long long)v);
     }
 }
 

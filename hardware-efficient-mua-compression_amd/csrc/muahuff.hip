@@ -109,6 +109,15 @@ struct mh_plan {
     uint2 *d_dtab2 = nullptr;
 };
 
+struct mh_sweep {
+    uint32_t C = 0, nh = 0, ni = 0;
+    std::vector<uint64_t> bounds;  // C * (ni + 1), sorted per channel
+    uint64_t n_tiles = 0, n_slots = 0;
+    uint64_t *d_ch_off = nullptr, *d_tile_start = nullptr, *d_slot_len = nullptr;
+    uint32_t *d_tile_ch = nullptr, *d_tile_n = nullptr, *d_tile_slot = nullptr;
+    unsigned long long *d_scratch = nullptr;
+};
+
 static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
                             uint8_t *peak, uint8_t *enc, hipStream_t st)
 {
@@ -409,6 +418,7 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
         a.tile_start = p->d_tile_start;
         a.tile_n = p->d_tile_n;
         a.hist = p->d_hist;
+        a.tile_slot = nullptr;
         const unsigned nt = (unsigned)p->n_tiles;
         if (p->info.S == 2)
             launch_hist<1>(a, p->n_tiles, st);  // byte-compare kernel: already at the read floor
@@ -600,6 +610,116 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
     else
         hipLaunchKernelGGL(mh::k_rebin<false>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
                            data, in_off, in_len, C, r, out, out_off);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_sweep_destroy(mh_sweep *w)
+{
+    if (!w) return MH_OK;
+    void *ptrs[] = {w->d_ch_off, w->d_tile_start, w->d_slot_len, w->d_tile_ch, w->d_tile_n, w->d_tile_slot,
+                    w->d_scratch};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete w;
+    return MH_OK;
+}
+
+int mh_sweep_create(mh_sweep **sweep, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                    const uint32_t *hist_bits, uint32_t nh)
+{
+    if (!sweep || !ch_off || !ch_len || !hist_bits) return fail(MH_ERR_ARG, "mh_sweep_create: NULL argument");
+    *sweep = nullptr;
+    if (C == 0 || nh == 0 || nh > 16) return fail(MH_ERR_ARG, "mh_sweep_create: C=%u nh=%u", C, nh);
+    for (uint32_t i = 0; i < nh; ++i)
+        if (hist_bits[i] > 30) return fail(MH_ERR_ARG, "hist_bits[%u]=%u outside 0..30", i, hist_bits[i]);
+    for (uint32_t c = 0; c < C; ++c)
+        if (ch_len[c] == 0)
+            return fail(MH_ERR_EMPTY_CHANNEL, "channel %u has no bins (the reference raises IndexError)", c);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MH_ERR_NO_DEVICE, "no HIP device visible (libmuahuff has no CPU fallback)");
+    mh_sweep *w = new (std::nothrow) mh_sweep;
+    if (!w) return fail(MH_ERR_ARG, "out of host memory");
+    w->C = C;
+    w->nh = nh;
+    w->ni = 2 * nh + 1;
+    const uint32_t np = w->ni + 1;
+    w->bounds.resize((size_t)C * np);
+    std::vector<uint32_t> tile_ch, tile_n, tile_slot;
+    std::vector<uint64_t> tile_start, slot_len((size_t)C * w->ni), off(ch_off, ch_off + C);
+    for (uint32_t c = 0; c < C; ++c) {
+        const uint64_t T = ch_len[c];
+        uint64_t *b = &w->bounds[(size_t)c * np];
+        uint32_t k = 0;
+        b[k++] = 0;
+        for (uint32_t i = 0; i < nh; ++i) {
+            const uint64_t lim = (uint64_t)1 << hist_bits[i];
+            const uint64_t cut = T < lim ? T : lim;  // functions_1.py:59-64
+            const uint64_t e = cut + T / 2;          // get_BR_with_approx_sort.py:180
+            b[k++] = cut;
+            b[k++] = e > T ? T : e;
+        }
+        b[k++] = T;
+        for (uint32_t i = 1; i < np; ++i)  // insertion sort, np <= 34
+            for (uint32_t j = i; j > 0 && b[j] < b[j - 1]; --j) {
+                const uint64_t t = b[j];
+                b[j] = b[j - 1];
+                b[j - 1] = t;
+            }
+        for (uint32_t j = 0; j < w->ni; ++j) {
+            const uint64_t lo = b[j], hi = b[j + 1], slot = (uint64_t)c * w->ni + j;
+            slot_len[slot] = hi - lo;
+            for (uint64_t first = lo; first < hi; first += kHistTile) {
+                tile_ch.push_back(c);
+                tile_slot.push_back((uint32_t)slot);
+                tile_start.push_back(first);
+                tile_n.push_back((uint32_t)(hi - first < kHistTile ? hi - first : kHistTile));
+            }
+        }
+    }
+    w->n_tiles = tile_ch.size();
+    w->n_slots = (uint64_t)C * w->ni;
+    int rc;
+    if ((rc = upload(&w->d_ch_off, off)) || (rc = upload(&w->d_tile_ch, tile_ch)) ||
+        (rc = upload(&w->d_tile_n, tile_n)) || (rc = upload(&w->d_tile_slot, tile_slot)) ||
+        (rc = upload(&w->d_tile_start, tile_start)) || (rc = upload(&w->d_slot_len, slot_len)) ||
+        (rc = alloc(&w->d_scratch, (size_t)w->n_slots * mh::kHistStride))) {
+        mh_sweep_destroy(w);
+        return rc;
+    }
+    *sweep = w;
+    return MH_OK;
+}
+
+int mh_sweep_info(const mh_sweep *w, uint32_t *n_intervals, uint64_t *bounds)
+{
+    if (!w) return fail(MH_ERR_ARG, "mh_sweep_info: NULL sweep");
+    if (n_intervals) *n_intervals = w->ni;
+    if (bounds) memcpy(bounds, w->bounds.data(), w->bounds.size() * sizeof(uint64_t));
+    return MH_OK;
+}
+
+int mh_sweep_run(mh_sweep *w, const uint8_t *data, uint64_t *hist, void *stream)
+{
+    if (!w || !data || !hist) return fail(MH_ERR_ARG, "mh_sweep_run: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    MH_HIP(hipMemsetAsync(w->d_scratch, 0, (size_t)w->n_slots * mh::kHistStride * sizeof(unsigned long long), st));
+    if (w->n_tiles) {
+        mh::HistArgs a;
+        a.data = data;
+        a.ch_off = w->d_ch_off;
+        a.tile_ch = w->d_tile_ch;
+        a.tile_start = w->d_tile_start;
+        a.tile_n = w->d_tile_n;
+        a.hist = w->d_scratch;
+        a.tile_slot = w->d_tile_slot;
+        hipLaunchKernelGGL(mh::k_hist2<4>, dim3((unsigned)w->n_tiles), dim3(256), 0, st, a, (uint32_t)MH_SWEEP_BINS);
+        MH_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(mh::k_sweep_finalize, dim3((unsigned)((w->n_slots + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned long long *)w->d_scratch, (const uint64_t *)w->d_slot_len,
+                       (uint32_t)w->n_slots, hist);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }

@@ -48,13 +48,35 @@ def sclv_tables(directories):
 
 
 class DeviceChannels:
-    """All channels of one bin period resident on the GPU; subsets are views by index."""
+    """All channels of one bin period resident on the GPU; subsets are views by index.
+    With fused=True one mh_sweep_run pass at construction serves every later request
+    (all S, all histogram sizes, all CV splits) from host-side integer tables."""
 
-    def __init__(self, datasets):
+    def __init__(self, datasets, fused=False):
         from ..container import ChannelSet
         self.flat = [ch for ds in datasets for ch in ds]
         self.base = np.cumsum([0] + [len(ds) for ds in datasets])  # dataset -> first flat index
         self.cs = ChannelSet.from_channels(self.flat)
+        self.sweep = None
+        if fused and self.flat:
+            import torch
+
+            from ..sweep import SweepHist
+            self.sweep = SweepHist(self.cs.ch_off, self.cs.ch_len, HIST_BITS).run(self.cs.data)
+            torch.cuda.synchronize()
+
+    def train_hist(self, idx, S, table):
+        """whole-channel histograms by symbol, float [len(idx), S] (:140-146)"""
+        from .. import MODE_NOSORT, WIN_FULL
+        if self.sweep is not None:
+            return self.sweep.train_hist(idx, S).astype(np.float64)
+        return self.measure(idx, S, 0, MODE_NOSORT, WIN_FULL, table)["post"]
+
+    def validation(self, idx, S, h, approx, table):
+        from .. import MODE_APPROX, MODE_NOSORT, WIN_REF_HALF
+        if self.sweep is not None:
+            return self.sweep.validation(idx, S, h, approx)
+        return self.measure(idx, S, h, MODE_APPROX if approx else MODE_NOSORT, WIN_REF_HALF, table)
 
     def measure(self, idx, S, h, mode, window, table):
         """mh_measure over the channels `idx` (flat indices) -> dict of host arrays."""
@@ -94,22 +116,21 @@ def split_indices(n_per_dataset, base, how_many_sabes, train_percentage):
 
 def evaluate(dev, train_idx, val_idx, S, table, BP, approx):
     """One (CV, BP, S) cell -> the dict the reference pickles (:138-334)."""
-    from .. import MODE_APPROX, MODE_NOSORT, WIN_FULL, WIN_REF_HALF
     from ..codec import bit_rate
     S = int(S)
     sclvs = np.array([np.asarray(r, dtype=np.float64) for r in table], dtype=object)  # :125
     n_train, n_val = len(train_idx), len(val_idx)
     # training histograms of the whole channel, sorted descending (:140-147)
-    tr = dev.measure(train_idx, S, 0, MODE_NOSORT, WIN_FULL, table)
+    tr = dev.train_hist(train_idx, S, table)
     histograms = np.zeros((S, n_train))
     for c in range(n_train):
-        histograms[:, c] = np.flip(np.sort(tr["post"][c]))
+        histograms[:, c] = np.flip(np.sort(tr[c]))
     # validation histograms per histogram size (:157-210)
     cal_mem, post_mem = [], []
     c_all = np.zeros((n_val, len(HIST_BITS)))
     e_all = np.zeros((n_val, len(HIST_BITS)))
     for hi, h in enumerate(HIST_BITS):
-        v = dev.measure(val_idx, S, h, MODE_APPROX if approx else MODE_NOSORT, WIN_REF_HALF, table)
+        v = dev.validation(val_idx, S, h, approx, table)
         c_all[:, hi] = v["cutoff"]
         e_all[:, hi] = v["cutoff"] + (v["length"] // 2)  # :180 int(len/2)
         cal_mem.append(np.ascontiguousarray(v["cal"].T))    # [S, n_val]
@@ -147,13 +168,15 @@ def evaluate(dev, train_idx, val_idx, S, table, BP, approx):
 
 
 def run(root_directory, approx, nb_CV_iterations=30, how_many_channels_Sabes=2000, train_percentage=50,
-        S_values=range(2, 11), write=True, verbose=True):
-    """Whole sweep.  Returns {(S, BP, CV): result dict}; writes the pickles when `write`."""
+        S_values=range(2, 11), write=True, verbose=True, fused=True):
+    """Whole sweep.  Returns {(S, BP, CV): result dict}; writes the pickles when `write`.
+    fused=True: one GPU pass per bin period (mh_sweep_run); fused=False: one mh_measure per
+    (CV, S, h) -- same results, kept as a cross-check."""
     d = read_directories(root_directory)
     all_binned, bin_vector, _datasets = load_binned(d["Formatted_data_path"], "train")
     results_dir = d["BR_approx_sort_results" if approx else "BR_no_sort_results"]
     tabs = sclv_tables(d)
-    devs = [DeviceChannels(all_binned[i]) for i in range(len(bin_vector))]
+    devs = [DeviceChannels(all_binned[i], fused=fused) for i in range(len(bin_vector))]
     out = {}
     for cv in np.arange(1, nb_CV_iterations, 1):  # 1 .. nb-1, as the reference (:70)
         for bp_i, BP in enumerate(bin_vector):

@@ -162,6 +162,25 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
              uint64_t max_len, uint32_t r, int saturate, void *out, const uint64_t *out_off,
              void *stream);
 
+/* ---- fused sweep histograms (all design points from ONE pass over the data) --------------
+ * The two BR scripts loop S = 2..10 and histogram sizes 2^h (get_BR_with_approx_sort.py:107,157)
+ * and re-read every validation channel for each of the 81 combinations, for each CV split.
+ * All of those histograms are differences of prefix histograms of min(x, 9) taken at
+ *   0, c_h = min(2^h, T), e_h = min(c_h + T/2, T), T        (h in hist_bits[0..nh))
+ * so one pass that histograms the 2*nh+1 intervals between the SORTED breakpoints of each
+ * channel serves every (S, h, CV): calibration histogram = H(c_h), post histogram =
+ * H(c_h + T/2) - H(c_h), training histogram = H(T); smaller S merge the top bins. */
+typedef struct mh_sweep mh_sweep; /* opaque */
+#define MH_SWEEP_BINS 10 /* histogram bins per interval: values clipped at 9 (S <= 10) */
+int mh_sweep_create(mh_sweep **sweep, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                    const uint32_t *hist_bits, uint32_t nh);
+int mh_sweep_destroy(mh_sweep *sweep);
+/* n_intervals = 2*nh+1; bounds (host, C*(n_intervals+1) entries, may be NULL) receives the
+ * sorted breakpoints of every channel: interval j of channel c is [bounds[j], bounds[j+1]) */
+int mh_sweep_info(const mh_sweep *sweep, uint32_t *n_intervals, uint64_t *bounds);
+/* hist (device): C * n_intervals * MH_SWEEP_BINS u64 counts, [channel][interval][bin] */
+int mh_sweep_run(mh_sweep *sweep, const uint8_t *data, uint64_t *hist, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

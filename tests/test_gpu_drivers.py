@@ -27,8 +27,9 @@ def _tree(tmp_path, z):
     return str(root), str(res_a), str(res_n)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("tag", ["approx", "nosort"])
-def test_sweep_driver_is_bit_exact(tmp_path, tag):
+def test_sweep_driver_is_bit_exact(tmp_path, tag, fused):
     import muahuff
     from muahuff.drivers import get_BR_no_sort, get_BR_with_approx_sort
     z, params = helpers.sweep()
@@ -36,7 +37,7 @@ def test_sweep_driver_is_bit_exact(tmp_path, tag):
     mod = get_BR_with_approx_sort if tag == "approx" else get_BR_no_sort
     np.random.seed(params["seed"])
     out = mod.run(root, nb_CV_iterations=params["nb_CV_iterations"],
-                  how_many_channels_Sabes=params["how_many_channels_Sabes"], verbose=False)
+                  how_many_channels_Sabes=params["how_many_channels_Sabes"], verbose=False, fused=fused)
     assert len(out) == 9 * 2 * (params["nb_CV_iterations"] - 1)
     for (S, BP, cv), res in out.items():
         key = "%s/S%d_BP%d_CV%d/" % (tag, S, BP, cv)
@@ -60,3 +61,40 @@ def test_chosen_system_driver(tmp_path):
     root, _, _ = _tree(tmp_path, z)
     got = tcs.run(root, "test", verbose=False)
     assert helpers.same_float(got, helpers.chosen_system())
+
+
+def test_fused_sweep_equals_per_design_point_measure():
+    """mh_sweep_run (one pass) against mh_measure at every (S, h) and against the oracle."""
+    import torch
+
+    import muahuff
+    import oracle
+    from muahuff import codec, container, sclv, sweep
+    rng = np.random.RandomState(8)
+    lens = [1, 3, 5, 9, 64, 100, 1023, 1024, 1025, 2047, 2050, 5000, 131072 + 77, 300001]
+    chans = [np.minimum(rng.poisson(float(np.exp(rng.uniform(-3, 2))), size=T), 255).astype(np.uint8) for T in lens]
+    chans[4][:] = 255
+    cs = container.ChannelSet.from_channels(chans)
+    sw = sweep.SweepHist(cs.ch_off, cs.ch_len).run(cs.data)
+    torch.cuda.synchronize()
+    idx = np.arange(len(chans))
+    host = cs.data.cpu().numpy()
+    for S in (2, 3, 5, 10):
+        tab = sclv.table(S)
+        want_train = np.stack([np.bincount(np.minimum(x, S - 1), minlength=S) for x in chans])
+        assert np.array_equal(sw.train_hist(idx, S), want_train)
+        for h in (2, 6, 10):
+            for approx in (True, False):
+                v = sw.validation(idx, S, h, approx)
+                plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, int(approx), muahuff.WIN_REF_HALF, tab)
+                m = plan.measure(cs.data)
+                torch.cuda.synchronize()
+                assert np.array_equal(v["cal"], m.cal_hist.cpu().numpy())
+                assert np.array_equal(v["post"], m.post_hist.cpu().numpy())
+                assert np.array_equal(v["skipped"], m.skipped.cpu().numpy())
+                assert np.array_equal(v["cutoff"], m.cutoff.cpu().numpy())
+                plan.close()
+                om = oracle.c.measure(host, cs.ch_off, cs.ch_len, oracle.c.Params(S, h, int(approx), 0, tab))
+                assert np.array_equal(v["post"].astype(np.uint64), om["post_mapped"])
+                assert np.array_equal(v["cal"].astype(np.uint32), om["cal_sorted"])
+    sw.close()
