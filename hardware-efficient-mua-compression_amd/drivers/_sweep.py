@@ -149,12 +149,11 @@ def evaluate(dev, train_idx, val_idx, S, table, BP, approx):
             vdot = cal_mem[hi].T @ cur.T
             post = post_mem[hi]
             k = np.argmin(vdot, axis=1) if n_val else np.zeros(0, dtype=np.int64)  # :281 first min
-            brs = []
-            for ch in range(n_val):
-                n = np.sum(post[:, ch])
-                bits = np.sum(cur[k[ch], :] * post[:, ch])
-                brs.append(bit_rate(bits, n, BP))  # :289-292
-            per_hist.append(brs)
+            # :284-292 for all channels at once: the sums are sums of integer-valued doubles
+            # (exact in any order), the two divisions are element-wise float64 as in the reference
+            n = post.sum(axis=0)
+            bits = (cur[k, :] * post.T).sum(axis=1)
+            per_hist.append(list(bit_rate(bits, n, BP)))
         stored_BRs.append(per_hist)
         if len(sclvs) != 1:  # :310-316 drop the encoder whose removal hurts the training set least
             cost = np.zeros(len(sclvs))
