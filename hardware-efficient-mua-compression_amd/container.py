@@ -51,6 +51,25 @@ class ChannelSet:
         return cls(torch.from_numpy(host).to(device), off, ln)
 
     @classmethod
+    def from_time_major(cls, samples, device="cuda"):
+        """samples: [T, C] uint8 (host array or device tensor), one row per time step with the
+        channels interleaved |CH1|CH2|...|CHN| -- the order an implant streams binned counts
+        (reference RTL compression phase, FPGA implementation/README.md:31).  De-interleaved on
+        the GPU (mh_deinterleave) into the channel-major layout the codec reads."""
+        import ctypes as ct
+
+        from . import _lib
+        t = samples if isinstance(samples, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(samples, np.uint8))
+        t = t.to(device).contiguous()
+        T, C = int(t.shape[0]), int(t.shape[1])
+        cs = cls.empty([T] * C, device=t.device)
+        d_off = torch.from_numpy(cs.ch_off.astype(np.int64)).to(t.device)
+        _lib.check(_lib.lib().mh_deinterleave(ct.c_void_p(t.data_ptr()), T, C, ct.c_void_p(cs.data.data_ptr()),
+                                              ct.c_void_p(d_off.data_ptr()),
+                                              ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return cs
+
+    @classmethod
     def empty(cls, lengths, device="cuda"):
         off, ln, total = layout(lengths)
         return cls(torch.zeros(total + ALIGN, dtype=torch.uint8, device=device), off, ln)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "mh_codec2.hpp"
+#include "mh_layout.hpp"
 #include "muahuff.h"
 
 namespace {
@@ -600,16 +601,33 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
 {
     if (!data || !in_off || !in_len || !out || !out_off || C == 0 || r == 0)
         return fail(MH_ERR_ARG, "mh_rebin: bad argument");
-    uint64_t bx = ((max_len + r - 1) / r + 255) / 256;
+    if (r > 4096) return fail(MH_ERR_ARG, "mh_rebin: r=%u above 4096", r);
+    const uint64_t bins_per_tile = mh::kRebinTileBytes / r;
+    uint64_t bx = ((max_len + r - 1) / r + bins_per_tile - 1) / bins_per_tile;
     if (bx == 0) bx = 1;
     if (bx > 4096) bx = 4096;
     const uint32_t by = C > 65535 ? 65535 : C;
     if (saturate)
-        hipLaunchKernelGGL(mh::k_rebin<true>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(mh::k_rebin2<true>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
                            data, in_off, in_len, C, r, out, out_off);
     else
-        hipLaunchKernelGGL(mh::k_rebin<false>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(mh::k_rebin2<false>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
                            data, in_off, in_len, C, r, out, out_off);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, const uint64_t *out_off,
+                    void *stream)
+{
+    if (!in || !out || !out_off || C == 0) return fail(MH_ERR_ARG, "mh_deinterleave: bad argument");
+    if (T == 0) return MH_OK;
+    uint64_t bx = (T + mh::kTrT - 1) / mh::kTrT;
+    if (bx > 2048) bx = 2048;
+    const uint32_t by = (C + mh::kTrC - 1) / mh::kTrC;
+    if (by > 65535) return fail(MH_ERR_ARG, "mh_deinterleave: C=%u too large", C);
+    hipLaunchKernelGGL(mh::k_deinterleave, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, out,
+                       out_off);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }

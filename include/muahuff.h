@@ -162,6 +162,13 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
              uint64_t max_len, uint32_t r, int saturate, void *out, const uint64_t *out_off,
              void *stream);
 
+/* Time-major interleaved samples -> the channel-major layout of a plan.  `in` holds T rows of C
+ * bytes, |CH1|CH2|...|CHN| per time step: the order in which an implant (and the reference's
+ * RTL in its compression phase, FPGA implementation/README.md:31) emits binned counts.
+ * Channel c is written to out + out_off[c] (T bytes).  in, out, out_off: device. */
+int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, const uint64_t *out_off,
+                    void *stream);
+
 /* ---- fused sweep histograms (all design points from ONE pass over the data) --------------
  * The two BR scripts loop S = 2..10 and histogram sizes 2^h (get_BR_with_approx_sort.py:107,157)
  * and re-read every validation channel for each of the 81 combinations, for each CV split.

@@ -277,3 +277,42 @@ def test_full_size_properties(mh, S, h, K_rows):
     bits_per_sample = float(e.ch_bits.sum()) / plan.window_samples
     assert 1.0 <= bits_per_sample <= float(tab.max())
     plan.close()
+
+
+def test_rebin_kernel_all_periods(mh):
+    """mh_rebin against the oracle for the reference's bin periods (1 ms data -> 5..100 ms) on
+    ragged channels, both output flavours (uint8 saturating like MATLAB, uint32 exact)."""
+    import ctypes as ct
+    rng = np.random.RandomState(12)
+    lens = [1, 4, 99, 100, 101, 32768, 32769, 100003, 250000]
+    chans = [rng.randint(0, 9, size=T).astype(np.uint8) for T in lens]
+    chans[3][:] = 255
+    cs = _cs(mh, chans)
+    lib = mh._lib.lib()
+    d_off = torch.from_numpy(cs.ch_off.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(cs.ch_len.astype(np.int64)).cuda()
+    for r in (1, 2, 5, 10, 20, 50, 100):
+        nb = [-(-T // r) for T in lens]
+        ooff = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int64)
+        d_ooff = torch.from_numpy(ooff).cuda()
+        for sat in (0, 1):
+            out = torch.zeros(sum(nb), dtype=torch.uint8 if sat else torch.int32, device="cuda")
+            mh._lib.check(lib.mh_rebin(ct.c_void_p(cs.data.data_ptr()), ct.c_void_p(d_off.data_ptr()),
+                                       ct.c_void_p(d_len.data_ptr()), len(lens), max(lens), r, sat,
+                                       ct.c_void_p(out.data_ptr()), ct.c_void_p(d_ooff.data_ptr()), None))
+            got = out.cpu().numpy()
+            for c, x in enumerate(chans):
+                want = OC.rebin_u8(x, r) if sat else OC.rebin_u32(x, r)
+                assert np.array_equal(got[ooff[c]:ooff[c] + nb[c]].astype(np.int64), want.astype(np.int64)), (r, sat, c)
+
+
+@pytest.mark.parametrize("T,C", [(1, 1), (255, 3), (256, 64), (1000, 96), (4097, 130), (70000, 17)])
+def test_deinterleave_time_major_stream(mh, T, C):
+    """|CH1|CH2|...|CHN| per time step -> channel-major, then the codec runs on it unchanged."""
+    rng = np.random.RandomState(T + C)
+    x = rng.randint(0, 6, size=(T, C)).astype(np.uint8)
+    cs = mh.container.ChannelSet.from_time_major(x)
+    torch.cuda.synchronize()
+    got = cs.to_channels()
+    for c in range(C):
+        assert np.array_equal(got[c], x[:, c]), c
