@@ -1,0 +1,157 @@
+"""Wire / file format of a compressed channel set (format revision 1), and the two calls that
+make the codec usable end to end: compress() and decompress().
+
+The reference never serialises a bitstream; this container is the
+build's own.  File layout (little-endian):
+
+    b"MUAHUFF1" | u32 header_len | header (UTF-8 JSON) | arrays, each padded to 8 bytes:
+        ch_len u64[C] | peak u8[C] | enc u8[C] | skipped u8[C] | ch_bits u64[C]
+        | seg_words u64[n_segments] | payload u32[total_words]
+
+The header carries everything a decoder needs to rebuild the plan: format revision, chunk
+geometry, S, h, mapper, window rule, seg_chunks and the K SCLV rows (the static codebooks).
+Per channel the stream only needs (peak, enc) -- the 3+2-bit RAM word of the reference's RTL
+(FPGA implementation/RAM.v:4) -- because codebooks are static and the symbol permutation is a
+closed form of the calibration peak.  `payload` is the dense concatenation of all segments in
+directory order (mh_compact); segment s starts at word sum(seg_words[:s]).
+"""
+import io
+import json
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+MAGIC = b"MUAHUFF1"
+FORMAT_REVISION = 1
+
+
+@dataclass
+class Compressed:
+    header: dict
+    ch_len: np.ndarray     # uint64 [C]
+    peak: np.ndarray       # uint8  [C]
+    enc: np.ndarray        # uint8  [C]
+    skipped: np.ndarray    # uint8  [C]
+    ch_bits: np.ndarray    # uint64 [C]  exact code bits (== reference histogram . SCLV)
+    seg_words: np.ndarray  # uint64 [n_segments]
+    payload: np.ndarray    # uint32 [sum(seg_words)]
+
+    @property
+    def payload_bits(self):
+        return int(self.ch_bits.sum())
+
+    @property
+    def container_bits(self):
+        return int(self.payload.size) * 32
+
+    def tobytes(self):
+        buf = io.BytesIO()
+        write(buf, self)
+        return buf.getvalue()
+
+
+def _arrays(c):
+    return [("ch_len", c.ch_len, np.uint64), ("peak", c.peak, np.uint8), ("enc", c.enc, np.uint8),
+            ("skipped", c.skipped, np.uint8), ("ch_bits", c.ch_bits, np.uint64),
+            ("seg_words", c.seg_words, np.uint64), ("payload", c.payload, np.uint32)]
+
+
+def write(f, c):
+    hdr = dict(c.header)
+    hdr["sizes"] = {name: int(np.asarray(a).size) for name, a, _ in _arrays(c)}
+    blob = json.dumps(hdr, sort_keys=True).encode()
+    f.write(MAGIC)
+    f.write(struct.pack("<I", len(blob)))
+    f.write(blob)
+    for _name, a, dt in _arrays(c):
+        raw = np.ascontiguousarray(a, dtype=dt).tobytes()
+        f.write(raw)
+        f.write(b"\0" * (-len(raw) % 8))
+
+
+def read(f):
+    if f.read(8) != MAGIC:
+        raise ValueError("not a MUAHUFF1 container")
+    (n,) = struct.unpack("<I", f.read(4))
+    hdr = json.loads(f.read(n).decode())
+    if hdr.get("format_revision") != FORMAT_REVISION:
+        raise ValueError("unsupported container revision %r" % hdr.get("format_revision"))
+    out = {}
+    for name, dt in (("ch_len", np.uint64), ("peak", np.uint8), ("enc", np.uint8), ("skipped", np.uint8),
+                     ("ch_bits", np.uint64), ("seg_words", np.uint64), ("payload", np.uint32)):
+        cnt = hdr["sizes"][name]
+        nbytes = cnt * np.dtype(dt).itemsize
+        raw = f.read(nbytes)
+        if len(raw) != nbytes:
+            raise ValueError("truncated container (%s)" % name)
+        f.read(-nbytes % 8)
+        out[name] = np.frombuffer(raw, dtype=dt).copy()
+    return Compressed(hdr, **out)
+
+
+def save(path, c):
+    with open(path, "wb") as f:
+        write(f, c)
+
+
+def load(path):
+    with open(path, "rb") as f:
+        return read(f)
+
+
+def make_header(S, h, mode, window, seg_chunks, sclv):
+    from . import _lib
+    sclv = np.asarray(sclv, dtype=np.uint8).reshape(-1, int(S))
+    return {"format_revision": FORMAT_REVISION, "piece": _lib.PIECE, "lanes": _lib.LANES, "rows": _lib.ROWS,
+            "S": int(S), "h": int(h), "mode": int(mode), "window": int(window), "seg_chunks": int(seg_chunks),
+            "K": int(sclv.shape[0]), "sclv": [[int(v) for v in r] for r in sclv]}
+
+
+# ---- GPU end-to-end ----------------------------------------------------------------------------
+def compress(cs, S, h, mode, sclv, window=None, seg_chunks=2):
+    """Calibrate + encode every channel of a ChannelSet on the GPU and bring the dense stream to
+    the host as a `Compressed`."""
+    import torch
+
+    from . import WIN_AFTER_CAL, codec
+    window = WIN_AFTER_CAL if window is None else window
+    plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, mode, window, sclv, seg_chunks=seg_chunks)
+    enc = plan.encode(cs.data)
+    dense, tot = plan.compact(enc)
+    torch.cuda.synchronize()
+    total = int(tot.item())
+    c = Compressed(make_header(S, h, mode, window, seg_chunks, sclv), cs.ch_len.copy(),
+                   enc.peak.cpu().numpy(), enc.enc.cpu().numpy(), enc.skipped.cpu().numpy(),
+                   enc.ch_bits.cpu().numpy().astype(np.uint64),
+                   enc.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments],
+                   dense.payload[:total].cpu().numpy().view(np.uint32).copy())
+    plan.close()
+    return c
+
+
+def decompress(c, device="cuda"):
+    """Inverse of compress(): a ChannelSet whose windows hold min(x, S-1) (bytes outside the
+    encoded windows are zero)."""
+    import torch
+
+    from . import codec
+    from .container import ChannelSet
+    hd = c.header
+    cs = ChannelSet.empty([int(n) for n in c.ch_len], device=device)
+    plan = codec.Plan(cs.ch_off, cs.ch_len, hd["S"], hd["h"], hd["mode"], hd["window"],
+                      np.array(hd["sclv"], np.uint8), seg_chunks=hd["seg_chunks"])
+    if plan.n_segments != len(c.seg_words):
+        raise ValueError("container directory does not match its header")
+    dev = cs.data.device
+    pay = torch.zeros(c.payload.size + 4, dtype=torch.int32, device=dev)
+    pay[:c.payload.size] = torch.from_numpy(c.payload.view(np.int32)).to(dev)
+    seg_off = np.concatenate([[0], np.cumsum(c.seg_words)[:-1]]).astype(np.int64) if len(c.seg_words) else np.zeros(1, np.int64)
+    e = codec.Encoded(pay, torch.from_numpy(c.seg_words.astype(np.int64)).to(dev),
+                      torch.from_numpy(c.ch_bits.astype(np.int64)).to(dev), torch.from_numpy(c.peak).to(dev),
+                      torch.from_numpy(c.enc).to(dev), torch.from_numpy(c.skipped).to(dev),
+                      torch.from_numpy(seg_off).to(dev), True)
+    plan.decode(e, cs.data)
+    torch.cuda.synchronize()
+    plan.close()
+    return cs

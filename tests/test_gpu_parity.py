@@ -316,3 +316,25 @@ def test_deinterleave_time_major_stream(mh, T, C):
     got = cs.to_channels()
     for c in range(C):
         assert np.array_equal(got[c], x[:, c]), c
+
+
+def test_compress_save_load_decompress(mh, tmp_path):
+    from muahuff import container_io as cio
+    rng = np.random.RandomState(21)
+    chans = _channels(rng, [70001, 16384, 5, 40000, 123457])
+    cs = _cs(mh, chans)
+    S, h, tab = 5, 6, helpers.sclv_tables()[5]
+    c = cio.compress(cs, S, h, 1, tab)
+    fn = tmp_path / "rec.mhf"
+    cio.save(fn, c)
+    d = cio.load(fn)
+    back = cio.decompress(d).to_channels()
+    for x, y in zip(chans, back):
+        cc = min(2 ** h, len(x))
+        assert np.array_equal(y[cc:], np.minimum(x[cc:], S - 1)) and not y[:cc].any()
+    # payload bits are the reference's histogram . SCLV, and the file is about that big
+    p = OC.Params(S, h, 1, OC.WIN_AFTER_CAL, tab)
+    data, off, ln = OC.flatten(chans)
+    assert np.array_equal(d.ch_bits, OC.measure(data, off, ln, p)["bits"])
+    assert d.container_bits < 1.08 * d.payload_bits + 64 * 32 * len(chans)
+    assert np.array_equal(OC.encode(data, off, ln, p)["ch_bits"], d.ch_bits)

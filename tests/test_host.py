@@ -115,3 +115,34 @@ def test_plan_argument_errors_without_gpu():
     rc = _lib.lib().mh_plan_create(ct.byref(h), off.ctypes.data, np.ones(1, np.uint64).ctypes.data, 1, 3, 6,
                                    1, 0, bad.ctypes.data, 1, 8)
     assert rc == _lib.ERR_SCLV
+
+
+def test_container_file_roundtrip_without_gpu(tmp_path):
+    from muahuff import container_io as cio
+    c = cio.Compressed(cio.make_header(3, 6, 1, 2, 2, [[1, 2, 2]]), np.array([100, 7], np.uint64),
+                       np.array([1, 0], np.uint8), np.array([0, 0], np.uint8), np.array([0, 1], np.uint8),
+                       np.array([51, 0], np.uint64), np.array([35], np.uint64), np.arange(35, dtype=np.uint32))
+    fn = tmp_path / "x.mhf"
+    cio.save(fn, c)
+    d = cio.load(fn)
+    assert d.header["S"] == 3 and d.header["sclv"] == [[1, 2, 2]] and d.header["format_revision"] == 1
+    for name in ("ch_len", "peak", "enc", "skipped", "ch_bits", "seg_words", "payload"):
+        assert np.array_equal(getattr(c, name), getattr(d, name)), name
+    assert d.container_bits == 35 * 32 and d.payload_bits == 51
+    with pytest.raises(ValueError):
+        cio.read(__import__("io").BytesIO(b"NOTMAGIC" + b"\0" * 16))
+
+
+def test_design_point_table_matches_reference_formula():
+    from muahuff import analysis
+    z, params = helpers.sweep()
+    res = {}
+    for key in z.files:
+        if key.startswith("approx/") and key.endswith("/BRs"):
+            S, BP, cv = [int(t[1:] if t[0] == "S" else t[2:]) for t in key.split("/")[1].split("_")]
+            res[(S, BP, cv)] = {"stored_all_var_BRs": z[key]}
+    tab = analysis.design_point_table(res)
+    # first row: BP=10, S=2, hist 2^2, 1 encoder, mean over channels and CVs (nan if any nan)
+    a = np.mean([np.mean(z["approx/S2_BP10_CV%d/BRs" % cv][0][0]) for cv in (1, 2)])
+    assert tab[0, :4].tolist() == [10, 2, 2, 1] and helpers.same_float(tab[0, 4], a)
+    assert tab.shape[1] == 6 and tab.shape[0] == 2 * 94 * 9
