@@ -151,15 +151,27 @@ static void launch_hist(const mh::HistArgs &a, uint64_t n_tiles, hipStream_t st)
 
 int g_ablate = 0;  // debug only (mhdbg_set_ablation); 0 in production
 
+// The launch helpers double as "prepare" helpers: with this thread-local flag set they only
+// raise the kernel's dynamic-LDS limit (hipFuncSetAttribute) and do not launch.  mh_plan_create
+// runs them once that way, so mh_encode / mh_decode issue nothing but stream work and stay
+// capturable into a hipGraph.
+thread_local bool g_prepare_only = false;
+static inline bool st_prepare_only_flag() { return g_prepare_only; }
+
 template <int LC, int PB, int ABL = 0>
 static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 {
     const size_t lds = ((size_t)mh::kEncSharedDw + 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw)) * sizeof(uint32_t);
     auto kern = mh::k_encode2<LC, PB, ABL>;
-    if (lds > 64 * 1024)
+    if (!st_prepare_only_flag()) {
+        hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
+    } else if (lds > 64 * 1024) {  // plan creation: raise the dynamic-LDS limit once, outside any capture
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
+        return MH_OK;
+    } else {
+        return MH_OK;
+    }
     MH_HIP(hipGetLastError());
     return MH_OK;
 }
@@ -169,12 +181,63 @@ static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
 {
     const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
     auto kern = mh::k_decode2<K, M, NR>;
-    if (lds > 64 * 1024)
+    if (!st_prepare_only_flag()) {
+        hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
+    } else if (lds > 64 * 1024) {
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
+        return MH_OK;
+    } else {
+        return MH_OK;
+    }
     MH_HIP(hipGetLastError());
     return MH_OK;
+}
+
+// lane-private LDS staging of the encoder: worst case 8*maxlen dwords per lane, capped at 32
+// (= 4 bits per sample averaged over a 256-sample sub-stream; a clipped spike-count channel at
+// S <= 10 stays well below that).  Chunks that outgrow it take the two-pass global slow path.
+static inline uint32_t enc_stage_dw(uint32_t maxlen) { return 8 * maxlen < 32 ? 8 * maxlen : 32; }
+
+static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t st)
+{
+    const uint32_t L = p->info.maxlen;
+    const bool pb3 = p->info.S <= 8;  // 3-bit pair packing when every symbol fits 3 bits
+    if (L <= 2 && pb3 && g_ablate) {  // debug ablations of the S<=3 kernel
+        switch (g_ablate) {
+        case 1: return launch_encode2<0, 3, 1>(a2, st);
+        case 2: return launch_encode2<0, 3, 2>(a2, st);
+        case 3: return launch_encode2<0, 3, 3>(a2, st);
+        default: return launch_encode2<0, 3, 4>(a2, st);
+        }
+    }
+    if (L <= 2) return pb3 ? launch_encode2<0, 3>(a2, st) : launch_encode2<0, 4>(a2, st);
+    if (L <= 4) return pb3 ? launch_encode2<1, 3>(a2, st) : launch_encode2<1, 4>(a2, st);
+    if (L <= 8) return pb3 ? launch_encode2<2, 3>(a2, st) : launch_encode2<2, 4>(a2, st);
+    return launch_encode2<3, 4>(a2, st);
+}
+
+static int dispatch_decode(const mh_plan *p, const mh::Dec2Args &a2, hipStream_t st)
+{
+    const uint32_t L = p->info.maxlen;
+    if (L <= 2) return launch_decode2<4, 4, 17>(a2, st);  // worst-case chunk = 1027 words: never oversize
+    if (L == 3) return launch_decode2<2, 2, 25>(a2, st);  // worst case 1539 words: never oversize
+    if (L <= 6) return launch_decode2<2, 2, 32>(a2, st);  // staged up to 4 bits/sample
+    return launch_decode2<1, 2, 32>(a2, st);
+}
+
+// raise the dynamic-LDS limits of the kernels this plan will launch (once, at plan creation)
+static int prepare_kernels(const mh_plan *p)
+{
+    mh::Enc2Args e{};
+    e.e.stage_dw = enc_stage_dw(p->info.maxlen);
+    mh::Dec2Args d{};
+    d.W = p->W;
+    g_prepare_only = true;
+    int rc = dispatch_encode(p, e, nullptr);
+    if (rc == MH_OK) rc = dispatch_decode(p, d, nullptr);
+    g_prepare_only = false;
+    return rc;
 }
 
 extern "C" {
@@ -373,7 +436,8 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
     p->info.K = K;
     p->info.seg_chunks = seg_chunks;
     p->info.maxlen = maxlen;
-    const int rc = plan_build(p, ch_off, ch_len, sclv);
+    int rc = plan_build(p, ch_off, ch_len, sclv);
+    if (rc == MH_OK) rc = prepare_kernels(p);
     if (rc != MH_OK) {
         mh_plan_destroy(p);
         return rc;
@@ -481,29 +545,13 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
     a.seg_words = seg_words;
     a.ch_bits = reinterpret_cast<unsigned long long *>(ch_bits);
     a.nseg = (uint32_t)p->info.n_segments;
-    // lane-private LDS staging: worst case 8*maxlen dwords per lane, capped at 32 (= 4 bits per
-    // sample averaged over a 256-sample sub-stream; a clipped spike-count channel at S <= 10 stays
-    // well below that).  Chunks that outgrow it take the encoder's two-pass global slow path.
-    a.stage_dw = 8 * p->info.maxlen < 32 ? 8 * p->info.maxlen : 32;
+    a.stage_dw = enc_stage_dw(p->info.maxlen);
     mh::Enc2Args a2;
     a2.e = a;
     a2.t.task_seg0 = p->d_task_seg0;
     a2.t.task_n = p->d_task_n;
     a2.t.ntask = p->n_tasks;
-    const uint32_t L = p->info.maxlen;
-    const bool pb3 = p->info.S <= 8;  // 3-bit pair packing when every symbol fits 3 bits
-    if (L <= 2 && pb3 && g_ablate) {  // debug ablations of the S<=3 kernel
-        switch (g_ablate) {
-        case 1: return launch_encode2<0, 3, 1>(a2, st);
-        case 2: return launch_encode2<0, 3, 2>(a2, st);
-        case 3: return launch_encode2<0, 3, 3>(a2, st);
-        default: return launch_encode2<0, 3, 4>(a2, st);
-        }
-    }
-    if (L <= 2) return pb3 ? launch_encode2<0, 3>(a2, st) : launch_encode2<0, 4>(a2, st);
-    if (L <= 4) return pb3 ? launch_encode2<1, 3>(a2, st) : launch_encode2<1, 4>(a2, st);
-    if (L <= 8) return pb3 ? launch_encode2<2, 3>(a2, st) : launch_encode2<2, 4>(a2, st);
-    return launch_encode2<3, 4>(a2, st);
+    return dispatch_encode(p, a2, st);
 }
 
 int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, const uint8_t *peak,
@@ -556,11 +604,7 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
     a2.t.ntask = p->n_tasks;
     a2.dtab2 = p->d_dtab2;
     a2.W = p->W;
-    const uint32_t L = p->info.maxlen;
-    if (L <= 2) return launch_decode2<4, 4, 17>(a2, st);  // worst-case chunk = 1027 words: never oversize
-    if (L == 3) return launch_decode2<2, 2, 25>(a2, st);  // worst case 1539 words: never oversize
-    if (L <= 6) return launch_decode2<2, 2, 32>(a2, st);  // staged up to 4 bits/sample
-    return launch_decode2<1, 2, 32>(a2, st);
+    return dispatch_decode(p, a2, st);
 }
 
 int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, uint32_t *dense,

@@ -338,3 +338,37 @@ def test_compress_save_load_decompress(mh, tmp_path):
     assert np.array_equal(d.ch_bits, OC.measure(data, off, ln, p)["bits"])
     assert d.container_bits < 1.08 * d.payload_bits + 64 * 32 * len(chans)
     assert np.array_equal(OC.encode(data, off, ln, p)["ch_bits"], d.ch_bits)
+
+
+@pytest.mark.parametrize("S", [3, 6])
+def test_encode_decode_are_graph_capturable(mh, S):
+    """mh_encode / mh_decode only enqueue stream work (no allocation, sync or attribute call), so a
+    whole round trip replays from a hipGraph (the launch-bound case for small recordings)."""
+    rng = np.random.RandomState(3)
+    chans = _channels(rng, [72000] * 12, 0.2, 3.0)
+    cs = _cs(mh, chans)
+    tab = helpers.sclv_tables()[S]
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, mh.WIN_AFTER_CAL, tab)
+    enc = plan.alloc_encoded()
+    out = torch.zeros_like(cs.data)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        plan.encode(cs.data, out=enc)  # warm-up outside capture
+        plan.decode(enc, out)
+    side.synchronize()
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan.encode(cs.data, out=enc)
+        plan.decode(enc, out)
+    ref_bits = enc.ch_bits.clone()
+    out.zero_()
+    enc.ch_bits.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(enc.ch_bits, ref_bits) and int(ref_bits.sum()) > 0
+    got = out.cpu().numpy()
+    for c, x in enumerate(chans):
+        o = int(cs.ch_off[c])
+        assert np.array_equal(got[o + 64:o + len(x)], np.minimum(x[64:], S - 1))
+    plan.close()
