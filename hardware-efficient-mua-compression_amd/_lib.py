@@ -3,7 +3,7 @@ import ctypes as ct
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libmuahuff.so")
+SO = os.environ.get("MUAHUFF_LIB", os.path.join(HERE, "libmuahuff.so"))  # override: A/B builds only
 
 MH_OK = 0
 ERR_ARG, ERR_EMPTY_CHANNEL, ERR_SCLV, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6

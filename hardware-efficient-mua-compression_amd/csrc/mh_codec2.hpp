@@ -36,7 +36,7 @@ constexpr uint32_t kEncSharedDw = 512 + 32;  // pair table (256 x uint2) + singl
 
 __host__ __device__ inline uint32_t enc2_wave_dwords(uint32_t stage_dw)
 {
-    return stage_dw * 64 + 64 + 32 + stage_dw * 64;  // staging + (carried tail + chunk image)
+    return 96 + stage_dw * 64;  // carried tail (64) + header room (32) + staging / image area
 }
 
 // Slow path for a chunk (m <= 16384 samples) whose sub-streams do not fit the capped LDS staging
@@ -121,6 +121,104 @@ __device__ __forceinline__ u32x4 load_row(const uint8_t *p)
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
 }
 
+// ---- per-wave LDS buffer of the encoder ------------------------------------------------------
+// buf[0,64)   words carried over from the previous chunk (not yet a whole 256-byte block)
+// buf[64,96)  room so that the 32-word chunk header always fits below R
+// R = buf+96  staging AND image area, 64*cap dwords:
+//   staging: lane l = 16*g + s keeps its j-th spilled dword at R[g*16*cap + j*16 + s]
+//   image:   header at buf[pend .. pend+32), payload right behind it, growing upwards.
+// The merge walks the four 16-lane groups in order.  A group's staged dwords (<= 16*cap) are
+// first pulled into registers by all 64 lanes (cap/4 each), then ORed into the payload.  The
+// payload written through group g ends at most at buf[pend+32 + 16*(g+1)*cap) <= R + 16*(g+1)*cap,
+// the start of group g+1's staging, so nothing still needed is ever overwritten: the image is
+// built IN PLACE and the wave needs half the LDS of a separate staging + image pair.
+__device__ __forceinline__ uint32_t *stage_lane_base(uint32_t *buf, uint32_t cap, int lane)
+{
+    return buf + 96 + (uint32_t)(lane >> 4) * 16 * cap + (lane & 15);
+}
+
+#define MH_WAVE_SYNC()                                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier()
+
+// NE >= cap/4: staged dwords one lane gathers per group
+template <int NE, int ABL>
+__device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uint32_t tot, uint32_t sp,
+                                                uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
+                                                uint32_t &words, uint32_t &bits)
+{
+    const uint32_t incl = wave_scan_incl(tot, lane);
+    const uint32_t P = incl - tot;
+    const uint32_t B = __shfl(incl, 63, 64);
+    const uint32_t nw = (B + 31) >> 5;
+    uint32_t *hdr = buf + pend;
+    uint32_t *pay = hdr + kHdrWords;
+    reinterpret_cast<uint16_t *>(hdr)[lane] = (uint16_t)tot;
+    const uint32_t *R = buf + 96;
+    const int sl = lane & 15, jq = lane >> 4;
+    uint32_t zeroed = 0;  // payload words [0, zeroed) are initialised
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        const int src = g * 16 + sl;
+        const uint32_t sp_s = __shfl(sp, src, 64), P_s = __shfl(P, src, 64);
+        const uint32_t *sg = R + (uint32_t)g * 16 * cap;
+        uint32_t vals[NE];
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t jj = (uint32_t)(r * 4 + jq);
+            vals[r] = jj < sp_s ? sg[jj * 16 + sl] : 0u;
+        }
+        MH_WAVE_SYNC();
+        const uint32_t w_end = (__shfl(incl, g * 16 + 15, 64) + 31) >> 5;
+        for (uint32_t i = zeroed + lane; i < w_end; i += 64) pay[i] = 0;
+        zeroed = w_end;
+        MH_WAVE_SYNC();
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            const uint32_t jj = (uint32_t)(r * 4 + jq);
+            if (jj < sp_s) {
+                const uint32_t pos = P_s + 32 * jj;
+                const uint64_t sh = (uint64_t)vals[r] << (pos & 31);
+                atomicOr(&pay[pos >> 5], (uint32_t)sh);
+                if ((uint32_t)(sh >> 32)) atomicOr(&pay[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+            }
+        }
+        MH_WAVE_SYNC();
+    }
+    // only whole, 256-byte-aligned blocks go to HBM (16 B per lane, non-temporal); the rest waits
+    const uint32_t total = pend + kHdrWords + nw;
+    const uint32_t nflush = total & ~63u;
+    if (ABL < 1)
+        for (uint32_t i = lane * 4; i < nflush; i += 256)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(buf + i),
+                                        reinterpret_cast<u32x4_u *>(dst + i));
+    const uint32_t tail = total - nflush;
+    uint32_t t = 0;
+    if ((uint32_t)lane < tail) t = buf[nflush + lane];
+    MH_WAVE_SYNC();
+    if ((uint32_t)lane < tail) buf[lane] = t;
+    MH_WAVE_SYNC();
+    dst += nflush;
+    pend = tail;
+    words = kHdrWords + nw;
+    bits = B;
+}
+
+// chunk whose sub-streams outgrew the staging: flush the carried tail, then the global slow path
+__device__ __forceinline__ void overflow_chunk(const uint8_t *src, uint32_t m, const uint2 *lut1, uint32_t *buf,
+                                               uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
+                                               uint32_t &words, uint32_t &bits)
+{
+    if ((uint32_t)lane < pend) dst[lane] = buf[lane];
+    MH_WAVE_SYNC();
+    dst += pend;
+    pend = 0;
+    const uint2 r = encode_chunk_slow(src, m, lut1, dst, lane);
+    words = r.x;
+    bits = r.y;
+    dst += words;
+}
+
 // One full chunk.  v[] is a rolling window: row k of this chunk sits in v[k & 7]; after it is
 // consumed the slot is refilled with the row 8 KiB further on (this chunk, then the next one).
 // ABL (debug ablation, 0 in production): 1 no global stores, 2 also no merge, 3 also no staging
@@ -128,19 +226,19 @@ __device__ __forceinline__ u32x4 load_row(const uint8_t *p)
 template <int LC, int PB, int ABL = 0>
 __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_t *__restrict__ cur,
                                                   bool has_next, const uint2 *lut2, const uint2 *lut1,
-                                                  uint32_t *stage, uint32_t cap, uint32_t *img,
-                                                  uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
-                                                  uint32_t &words, uint32_t &bits)
+                                                  uint32_t *buf, uint32_t cap, uint32_t *__restrict__ &dst,
+                                                  uint32_t &pend, int lane, uint32_t &words, uint32_t &bits)
 {
     uint64_t acc = 0;
     uint32_t nb = 0, sp = 0;
+    uint32_t *st = stage_lane_base(buf, cap, lane);
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
-#define MH_FLUSH()                                                        \
-    if (nb >= 32) {                                                       \
-        if (ABL < 3 && sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;   \
-        acc >>= 32;                                                       \
-        nb -= 32;                                                         \
-        ++sp;                                                             \
+#define MH_FLUSH()                                               \
+    if (nb >= 32) {                                              \
+        if (ABL < 3 && sp < cap) st[sp * 16] = (uint32_t)acc;    \
+        acc >>= 32;                                              \
+        nb -= 32;                                                \
+        ++sp;                                                    \
     }
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
@@ -186,60 +284,73 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
     }
     const uint32_t tot = sp * 32 + nb;
     if (nb > 0) {
-        if (sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;
+        if (sp < cap) st[sp * 16] = (uint32_t)acc;
         ++sp;
     }
-    if (__any(sp > cap)) {  // some sub-stream outgrew the LDS staging: redo this chunk the slow way
-        if ((uint32_t)lane < pend) dst[lane] = img[lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        dst += pend;
-        pend = 0;
-        const uint2 r = encode_chunk_slow(cur, kChunk, lut1, dst, lane);
-        words = r.x;
-        bits = r.y;
-        dst += words;
+    MH_WAVE_SYNC();
+    if (__any(sp > cap)) {
+        overflow_chunk(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
         return;
     }
-    const uint32_t incl = wave_scan_incl(tot, lane);
-    const uint32_t P = incl - tot;
-    const uint32_t B = __shfl(incl, 63, 64);
-    const uint32_t nw = (B + 31) >> 5;
-    // The chunk image is built right behind the `pend` words carried over from the previous
-    // chunk, so that only whole, 256-byte-aligned blocks ever go to HBM (16 B per lane).
-    uint32_t *hdr = img + pend;
-    uint32_t *pay = hdr + kHdrWords;
-    for (uint32_t i = lane; i < nw; i += 64) pay[i] = 0;
-    reinterpret_cast<uint16_t *>(hdr)[lane] = (uint16_t)tot;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = 0; j < sp; ++j) {
-        const uint32_t w = stage[j * 64 + lane];
-        const uint32_t pos = P + 32 * j;
-        const uint64_t sh = (uint64_t)w << (pos & 31);
-        atomicOr(&pay[pos >> 5], (uint32_t)sh);
-        if ((uint32_t)(sh >> 32)) atomicOr(&pay[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+    merge_and_flush<(LC == 0 ? 4 : 8), ABL>(buf, cap, tot, sp, dst, pend, lane, words, bits);
+}
+
+// Last, partial chunk of a channel (m < 16384 samples): per-symbol front end with validity
+// predicates, same staging and the same in-place merge.
+// Returns {words, bits, new pend, words by which dst advanced}.
+template <int NE>
+__device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ src, uint32_t m,
+                                                   const uint2 *lut1, uint32_t *buf, uint32_t cap,
+                                                   uint32_t *__restrict__ dst0, uint32_t pend, int lane)
+{
+    uint32_t *__restrict__ dst = dst0;
+    uint32_t words, bits;
+    uint64_t acc = 0;
+    uint32_t nb = 0, sp = 0;
+    uint32_t *st = stage_lane_base(buf, cap, lane);
+#pragma unroll 1
+    for (int k = 0; k < kRows; ++k) {
+        const uint32_t base = ((uint32_t)k * kLanes + lane) * MH_PIECE;
+        const int c = (int)m - (int)base;
+        const int cnt = c < 0 ? 0 : (c > MH_PIECE ? MH_PIECE : c);
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (cnt == MH_PIECE) {
+            x = *reinterpret_cast<const u32x4_u *>(src + base);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MH_PIECE; ++i)
+                if (i < cnt) x[i >> 2] |= (uint32_t)src[base + i] << (8 * (i & 3));
+        }
+#pragma unroll
+        for (int i = 0; i < MH_PIECE; ++i) {
+            if (i < cnt) {
+                uint32_t b = (x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                b = b > 15u ? 15u : b;
+                const uint2 e = lut1[b];
+                acc |= (uint64_t)e.x << nb;
+                nb += e.y;
+            }
+            if ((i + 1) % 3 == 0 || i == MH_PIECE - 1) {  // <= 3 symbols of <= 9 bits between checks
+                if (nb >= 32) {
+                    if (sp < cap) st[sp * 16] = (uint32_t)acc;
+                    acc >>= 32;
+                    nb -= 32;
+                    ++sp;
+                }
+            }
+        }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t total = pend + kHdrWords + nw;
-    const uint32_t nflush = total & ~63u;
-    if (ABL < 1)
-        for (uint32_t i = lane * 4; i < nflush; i += 256)
-            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(img + i),
-                                        reinterpret_cast<u32x4_u *>(dst + i));
-    const uint32_t tail = total - nflush;
-    uint32_t t = 0;
-    if ((uint32_t)lane < tail) t = img[nflush + lane];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if ((uint32_t)lane < tail) img[lane] = t;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    dst += nflush;
-    pend = tail;
-    words = kHdrWords + nw;
-    bits = B;
+    const uint32_t tot = sp * 32 + nb;
+    if (nb > 0) {
+        if (sp < cap) st[sp * 16] = (uint32_t)acc;
+        ++sp;
+    }
+    MH_WAVE_SYNC();
+    if (__any(sp > cap))
+        overflow_chunk(src, m, lut1, buf, dst, pend, lane, words, bits);
+    else
+        merge_and_flush<NE, 0>(buf, cap, tot, sp, dst, pend, lane, words, bits);
+    return make_uint4(words, bits, pend, (uint32_t)(dst - dst0));
 }
 
 template <int LC, int PB, int ABL = 0>
@@ -267,12 +378,12 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     __syncthreads();
     if ((uint32_t)wave >= nseg) return;
     const uint32_t seg = seg0 + wave;
-    uint32_t *lds = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(a.e.stage_dw);
-    uint32_t *stage = lds;
-    uint32_t *img = stage + a.e.stage_dw * 64;
+    const uint32_t cap = a.e.stage_dw;
+    uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
     const uint8_t *src = a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg];
     const uint64_t n = a.e.seg_n[seg];
-    uint32_t *dst = a.e.payload + a.e.seg_off[seg];
+    uint32_t *__restrict__ out = a.e.payload + a.e.seg_off[seg];  // next unflushed word
+    uint32_t pend = 0;                                            // words waiting in LDS behind `out`
     const uint32_t nfull = (uint32_t)(n / kChunk);
     const uint32_t rem = (uint32_t)(n % kChunk);
     uint64_t words = 0, bits = 0;
@@ -280,31 +391,23 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
         u32x4 v[kWin];
 #pragma unroll
         for (int k = 0; k < kWin; ++k) v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
-        uint32_t *__restrict__ out = dst;  // next unflushed word (always 256-byte aligned)
-        uint32_t pend = 0;                 // words waiting in LDS behind `out`
         for (uint32_t c = 0; c < nfull; ++c) {
             uint32_t w, b;
-            encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, lut1, stage,
-                                           a.e.stage_dw, img, out, pend, lane, w, b);
+            encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, lut1, buf, cap,
+                                           out, pend, lane, w, b);
             words += w;
             bits += b;
         }
-        if (ABL < 1 && (uint32_t)lane < pend) out[lane] = img[lane];  // segment tail
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
     if (rem) {
-        uint32_t w, b;
-        encode_chunk<3, false>(src + (size_t)nfull * kChunk, rem, lut1, stage, img + 64, dst + words, lane, w,
-                               b, a.e.stage_dw);
-        if (w == 0) {  // staging overflow in the partial chunk
-            const uint2 r = encode_chunk_slow(src + (size_t)nfull * kChunk, rem, lut1, dst + words, lane);
-            w = r.x;
-            b = r.y;
-        }
-        words += w;
-        bits += b;
+        const uint4 r = encode_partial_chunk<(LC == 0 ? 4 : 8)>(src + (size_t)nfull * kChunk, rem, lut1, buf, cap,
+                                                                 out, pend, lane);
+        words += r.x;
+        bits += r.y;
+        pend = r.z;
+        out += r.w;
     }
+    if (ABL < 1 && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
     if (lane == 0) {
         a.e.seg_words[seg] = words;
         atomicAdd(&a.e.ch_bits[ch], (unsigned long long)bits);
