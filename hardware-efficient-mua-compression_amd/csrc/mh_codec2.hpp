@@ -421,7 +421,8 @@ struct Dtab2Args {
     const uint8_t *peak, *enc, *sclv;
     const uint32_t *codes;
     uint32_t C, S, mode, W, K;
-    uint2 *dtab2;  // C << W entries {K symbol bytes, bits consumed}
+    void *dtab2;  // C << W entries: K == 4 -> uint2 {4 symbol bytes, bits consumed};
+                  // K <= 2 -> u32 (symbol bytes in the low half, bits consumed in the high half)
 };
 
 // Entry idx = the next W stream bits; it decodes exactly K symbols (W >= K * maxlen, and the
@@ -451,18 +452,26 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
             bytes |= sym[hit] << (8 * j);
             pos += clen[hit];
         }
-        a.dtab2[((size_t)ch << W) + idx] = make_uint2(bytes, pos);
+        if (K == 4)
+            reinterpret_cast<uint2 *>(a.dtab2)[((size_t)ch << W) + idx] = make_uint2(bytes, pos);
+        else
+            reinterpret_cast<uint32_t *>(a.dtab2)[((size_t)ch << W) + idx] = bytes | (pos << 16);
     }
 }
 
 struct Dec2Args {
     DecArgs d;
     TaskArgs t;
-    const uint2 *dtab2;
+    const void *dtab2;
     uint32_t W;  // table index bits
 };
 
-__host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W) { return (2u << W) + kDtab / 4; }
+// LDS dwords of the workgroup-shared tables: multi-symbol table (2 dwords per entry for K = 4,
+// 1 otherwise) + the 512-byte per-symbol table used by partial / oversize chunks
+__host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W, uint32_t K)
+{
+    return ((K == 4 ? 2u : 1u) << W) + kDtab / 4;
+}
 
 // Per-chunk pipeline state: the scanned header of the chunk about to be decoded.
 struct ChunkHdr {
@@ -485,7 +494,7 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw, int lane)
 // The loop issues no global load, so nothing in it waits on the vector-memory counter (which
 // also counts the 16-byte output stores).
 template <int K, int M>
-__device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint2 *tab, uint32_t maskW,
+__device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *tabw, uint32_t maskW,
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
                                                     int lane)
 {
@@ -507,9 +516,16 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint2 *tab
             uint32_t w = 0;
 #pragma unroll
             for (int i = 0; i < 4 / K; ++i) {
-                const uint2 e = tab[(uint32_t)(buf >> bp) & maskW];
-                w |= e.x << (8 * K * i);
-                bp += e.y;
+                const uint32_t idx = (uint32_t)(buf >> bp) & maskW;
+                if (K == 4) {
+                    const uint2 e = reinterpret_cast<const uint2 *>(tabw)[idx];
+                    w = e.x;
+                    bp += e.y;
+                } else {
+                    const uint32_t e = tabw[idx];
+                    w |= (e & 0xFFFFu) << (8 * K * i);
+                    bp += e >> 16;
+                }
                 if ((d * (4 / K) + i + 1) % M == 0) { MH_REFILL(); }
             }
             o[d] = w;
@@ -535,11 +551,12 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
     const uint32_t nseg = a.t.task_n[task];
     const uint32_t ch = a.d.seg_ch[seg0];
     const uint32_t W = a.W;
-    uint2 *tab = reinterpret_cast<uint2 *>(smem);
-    uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (2u << W));
+    constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
+    uint32_t *tab = smem;
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (kEntDw << W));
     {
-        const uint2 *g = a.dtab2 + ((size_t)ch << W);
-        for (uint32_t i = threadIdx.x; i < (1u << W); i += 256) tab[i] = g[i];
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(a.dtab2) + (((size_t)ch << W) * kEntDw);
+        for (uint32_t i = threadIdx.x; i < (kEntDw << W); i += 256) tab[i] = g[i];
         if (threadIdx.x < kDtab / 8)
             reinterpret_cast<uint2 *>(tab1)[threadIdx.x] =
                 reinterpret_cast<const uint2 *>(a.d.dtab + (size_t)ch * kDtab)[threadIdx.x];
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
     if ((uint32_t)wave >= nseg) return;
     const uint32_t seg = seg0 + wave;
     constexpr uint32_t kCap = NR * 64;
-    uint32_t *stage = smem + dec2_shared_dwords(W) + (size_t)wave * kCap;
+    uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * kCap;
     const uint32_t maskW = (1u << W) - 1u;
     const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
     const uint32_t *in = a.d.payload + a.d.seg_off[seg];

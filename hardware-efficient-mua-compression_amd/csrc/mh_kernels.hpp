@@ -533,9 +533,12 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t *payload, const 
     const uint32_t seg = blockIdx.x;
     const uint64_t n = seg_words[seg], d0 = dense_off[seg];
     if (d0 + n > dense_cap) return;  // host checks total_words afterwards
-    const uint32_t *src = payload + seg_off[seg];
-    uint32_t *dst = dense + d0;
-    for (uint64_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    const uint32_t *src = payload + seg_off[seg];  // slots start on 128-byte lines
+    uint32_t *dst = dense + d0;                    // word-aligned only: unaligned 16-byte stores
+    const uint64_t nv = n >> 2;
+    for (uint64_t i = threadIdx.x; i < nv; i += 256)
+        *reinterpret_cast<u32x4_u *>(dst + 4 * i) = *reinterpret_cast<const u32x4_u *>(src + 4 * i);
+    if (threadIdx.x < (n & 3)) dst[4 * nv + threadIdx.x] = src[4 * nv + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------

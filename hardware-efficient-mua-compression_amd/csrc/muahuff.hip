@@ -107,7 +107,7 @@ struct mh_plan {
     uint32_t n_tasks = 0;
     uint32_t W = 0;  // decode table index bits
     uint32_t dec_K = 4;  // symbols per decode-table lookup
-    uint2 *d_dtab2 = nullptr;
+    uint2 *d_dtab2 = nullptr;  // sized for 8-byte entries; K <= 2 plans use half of it
 };
 
 struct mh_sweep {
@@ -179,7 +179,7 @@ static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 template <int K, int M, int NR>
 static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
 {
-    const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
+    const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
     auto kern = mh::k_decode2<K, M, NR>;
     if (!st_prepare_only_flag()) {
         hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
