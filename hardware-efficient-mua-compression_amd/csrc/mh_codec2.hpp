@@ -423,6 +423,8 @@ struct Dtab2Args {
     uint32_t C, S, mode, W, K;
     void *dtab2;  // C << W entries: K == 4 -> uint2 {4 symbol bytes, bits consumed};
                   // K <= 2 -> u32 (symbol bytes in the low half, bits consumed in the high half)
+    uint8_t *dtab;  // C*512 per-symbol table: symbol | len << 4, indexed by the next maxlen bits
+    uint8_t *dlen;  // C : max code length of the channel's encoder
 };
 
 // Entry idx = the next W stream bits; it decodes exactly K symbols (W >= K * maxlen, and the
@@ -441,6 +443,16 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
         sym[threadIdx.x] = (uint32_t)symbol_of_rank((int)a.mode, S, p, (int)threadIdx.x);
     }
     __syncthreads();
+    {   // per-symbol table (partial and oversize chunks)
+        const uint32_t L = clen[S - 1];  // rows are non-decreasing
+        if (threadIdx.x == 0) a.dlen[ch] = (uint8_t)L;
+        for (uint32_t j = threadIdx.x; j < (1u << L); j += 256) {
+            uint8_t e = 0;
+            for (int r = 0; r < S; ++r)
+                if ((j & ((1u << clen[r]) - 1u)) == code[r]) e = (uint8_t)(sym[r] | (clen[r] << 4));
+            a.dtab[(size_t)ch * kDtab + j] = e;
+        }
+    }
     for (uint32_t idx = threadIdx.x; idx < (1u << W); idx += 256) {
         uint32_t pos = 0, bytes = 0;
         for (int j = 0; j < K; ++j) {

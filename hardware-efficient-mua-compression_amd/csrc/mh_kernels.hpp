@@ -31,6 +31,11 @@ struct CalArgs {
     uint32_t *cal_sorted;      // C*S, may be NULL
     uint8_t *peak, *enc;       // never NULL (plan scratch when the caller passes NULL)
     uint2 *lut;                // C*16 {code_rev, len} indexed by min(raw value, 15)
+    // folded-in initialisation (saves separate memset / memcpy launches); each may be NULL
+    unsigned long long *zero_hist;  // [C][16] window-histogram scratch to clear
+    unsigned long long *zero_bits;  // [C] per-channel bit totals to clear
+    const uint8_t *skip_src;        // plan's skip flags ...
+    uint8_t *skip_dst;              // ... copied to the caller's array
 };
 
 __global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
@@ -92,7 +97,10 @@ __global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
         if (a.cutoff) a.cutoff[ch] = c;
         a.peak[ch] = (uint8_t)p;
         a.enc[ch] = (uint8_t)best_k;
+        if (a.zero_bits) a.zero_bits[ch] = 0;
+        if (a.skip_dst) a.skip_dst[ch] = a.skip_src[ch];
     }
+    if (a.zero_hist && lane < kHistStride) a.zero_hist[(size_t)ch * kHistStride + lane] = 0;
     if (a.cal_sorted && lane < S) {
         uint32_t v = 0;
 #pragma unroll

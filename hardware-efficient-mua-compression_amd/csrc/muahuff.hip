@@ -120,9 +120,14 @@ struct mh_sweep {
 };
 
 static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
-                            uint8_t *peak, uint8_t *enc, hipStream_t st)
+                            uint8_t *peak, uint8_t *enc, hipStream_t st, unsigned long long *zero_hist,
+                            unsigned long long *zero_bits, uint8_t *skip_dst)
 {
     mh::CalArgs a;
+    a.zero_hist = zero_hist;
+    a.zero_bits = zero_bits;
+    a.skip_src = p->d_skip;
+    a.skip_dst = skip_dst;
     a.data = data;
     a.ch_off = p->d_ch_off;
     a.ch_len = p->d_ch_len;
@@ -472,9 +477,8 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
     if (!p || !data) return fail(MH_ERR_ARG, "mh_measure: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
-    int rc = launch_calibrate(p, data, cutoff, cal_hist, pk, en, st);
+    int rc = launch_calibrate(p, data, cutoff, cal_hist, pk, en, st, p->d_hist, nullptr, nullptr);
     if (rc) return rc;
-    MH_HIP(hipMemsetAsync(p->d_hist, 0, (size_t)p->info.C * mh::kHistStride * sizeof(unsigned long long), st));
     if (p->n_tiles) {
         mh::HistArgs a;
         a.data = data;
@@ -526,11 +530,9 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
                     (unsigned long long)p->info.payload_cap_words);
     hipStream_t st = (hipStream_t)stream;
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
-    int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st);
+    int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st, nullptr,
+                              reinterpret_cast<unsigned long long *>(ch_bits), skipped);
     if (rc) return rc;
-    MH_HIP(hipMemsetAsync(ch_bits, 0, (size_t)p->info.C * sizeof(uint64_t), st));
-    if (skipped)
-        MH_HIP(hipMemcpyAsync(skipped, p->d_skip, p->info.C, hipMemcpyDeviceToDevice, st));
     if (p->info.n_segments == 0) return MH_OK;
     mh::EncArgs a;
     a.data = data;
@@ -559,18 +561,6 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
 {
     if (!p || !payload || !peak || !enc || !out) return fail(MH_ERR_ARG, "mh_decode: NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    mh::DtabArgs t;
-    t.peak = peak;
-    t.enc = enc;
-    t.sclv = p->d_sclv;
-    t.codes = p->d_codes;
-    t.C = p->info.C;
-    t.S = p->info.S;
-    t.mode = p->info.mode;
-    t.dtab = p->d_dtab;
-    t.dlen = p->d_dlen;
-    hipLaunchKernelGGL(mh::k_build_dtab, dim3(t.C), dim3(64), 0, st, t);
-    MH_HIP(hipGetLastError());
     if (p->info.n_segments == 0) return MH_OK;
     mh::DecArgs a;
     a.payload = payload;
@@ -595,6 +585,8 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
     t2.W = p->W;
     t2.K = p->dec_K;
     t2.dtab2 = p->d_dtab2;
+    t2.dtab = p->d_dtab;
+    t2.dlen = p->d_dlen;
     hipLaunchKernelGGL(mh::k_build_dtab2, dim3(t2.C), dim3(256), 0, st, t2);
     MH_HIP(hipGetLastError());
     mh::Dec2Args a2;
