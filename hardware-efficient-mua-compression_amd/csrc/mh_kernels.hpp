@@ -1,15 +1,13 @@
 // mh_kernels.hpp -- hand-written gfx950 kernels of the hot path.
 //
 //   k_calibrate      one wave per channel: cutoff, calibration histogram, peak, permutation,
-//                    first-min encoder, per-channel encode LUT
-//   k_hist<NS>       window histogram, byte-parallel compares, 16 B/lane coalesced reads
+//                    first-min encoder, per-channel encode LUT (also clears per-call scratch)
+//   k_hist<NS>       window histogram for S <= 3, byte-parallel compares, 16 B/lane reads
 //   k_finalize       rank-map the histogram, bits = SCLV[enc] . post
-//   k_encode<FI>     one wave per segment: LUT lookup, per-lane bit accumulation, LDS staging,
-//                    wave prefix sum of sub-stream lengths, LDS merge, coalesced flush
-//   k_build_dtab     per-channel decode tables from (peak, enc)
-//   k_decode<FI>     one wave per segment: one lane per sub-stream, table decode, 16 B stores
+//   decode_chunk     per-symbol decoder straight from global memory (partial / oversize chunks)
 //   k_scan_words / k_compact   dense re-packing of the segment slots
-//   k_synth / k_rebin          synthetic MUA generator, per-channel re-binning
+//   k_synth          synthetic MUA generator
+// The encoder / decoder proper are in mh_codec2.hpp, layout kernels in mh_layout.hpp.
 //
 // All integer / bit work, HBM-bound: no MFMA anywhere.
 #pragma once
@@ -250,169 +248,9 @@ struct EncArgs {
     uint32_t stage_dw;  // staging dwords per lane = 8 * maxlen (256 samples * maxlen / 32)
 };
 
-// LDS carve per wave (dwords): [0,32) LUT, then staging [stage_dw][64], then the chunk image
-// [32 header + stage_dw*64 payload]
-__host__ __device__ inline uint32_t enc_wave_dwords(uint32_t stage_dw)
-{
-    return 32 + stage_dw * 64 + 32 + stage_dw * 64;
-}
-
-template <int FI, bool FULL>
-__device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ src, uint32_t m,
-                                             const uint2 *lut, uint32_t *stage, uint32_t *img,
-                                             uint32_t *__restrict__ dst, int lane,
-                                             uint32_t &words, uint32_t &bits,
-                                             uint32_t cap = 0xFFFFFFFFu)
-{
-    u32x4 v[kRows];
-    int cnt[kRows];
-#pragma unroll
-    for (int k = 0; k < kRows; ++k) {
-        const uint32_t base = ((uint32_t)k * kLanes + lane) * MH_PIECE;
-        if (FULL) {
-            v[k] = *reinterpret_cast<const u32x4_u *>(src + base);
-            cnt[k] = MH_PIECE;
-        } else {
-            const int c = (int)m - (int)base;
-            cnt[k] = c < 0 ? 0 : (c > MH_PIECE ? MH_PIECE : c);
-            u32x4 t = {0u, 0u, 0u, 0u};
-            if (cnt[k] == MH_PIECE) {
-                t = *reinterpret_cast<const u32x4_u *>(src + base);
-            } else {
-#pragma unroll
-                for (int i = 0; i < MH_PIECE; ++i)
-                    if (i < cnt[k]) t[i >> 2] |= (uint32_t)src[base + i] << (8 * (i & 3));
-            }
-            v[k] = t;
-        }
-    }
-    // per-lane bit accumulation; every staged dword goes to stage[j*64 + lane]
-    uint64_t acc = 0;
-    uint32_t nb = 0, sp = 0;
-#pragma unroll
-    for (int k = 0; k < kRows; ++k) {
-#pragma unroll
-        for (int i = 0; i < MH_PIECE; ++i) {
-            if (FULL || i < cnt[k]) {
-                uint32_t b = (v[k][i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                b = b > 15u ? 15u : b;
-                const uint2 e = lut[b];
-                acc |= (uint64_t)e.x << nb;
-                nb += e.y;
-            }
-            if ((i + 1) % FI == 0 || i == MH_PIECE - 1) {
-                if (nb >= 32) {
-                    if (sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;
-                    acc >>= 32;
-                    nb -= 32;
-                    ++sp;
-                }
-            }
-        }
-    }
-    const uint32_t tot = sp * 32 + nb;  // exact code bits of this sub-stream
-    if (nb > 0) {
-        if (sp < cap) stage[sp * 64 + lane] = (uint32_t)acc;
-        ++sp;
-    }
-    if (__any(sp > cap)) {  // LDS staging too small for this chunk: the caller takes the slow path
-        words = 0;
-        bits = 0;
-        return;
-    }
-    // sub-stream placement: exclusive prefix over lanes
-    const uint32_t incl = wave_scan_incl(tot, lane);
-    const uint32_t P = incl - tot;
-    const uint32_t B = __shfl(incl, 63, 64);
-    const uint32_t nw = (B + 31) >> 5;
-    uint32_t *pay = img + kHdrWords;
-    for (uint32_t i = lane; i < nw; i += 64) pay[i] = 0;
-    reinterpret_cast<uint16_t *>(img)[lane] = (uint16_t)tot;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = 0; j < sp; ++j) {
-        const uint32_t w = stage[j * 64 + lane];
-        const uint32_t pos = P + 32 * j;
-        const uint64_t sh = (uint64_t)w << (pos & 31);
-        atomicOr(&pay[pos >> 5], (uint32_t)sh);
-        if ((uint32_t)(sh >> 32)) atomicOr(&pay[(pos >> 5) + 1], (uint32_t)(sh >> 32));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t total = kHdrWords + nw;
-    for (uint32_t i = lane; i < total; i += 64) dst[i] = img[i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    words = total;
-    bits = B;
-}
-
-template <int FI>
-__global__ __launch_bounds__(256) void k_encode(EncArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (seg >= a.nseg) return;
-    uint32_t *lds = smem + (size_t)wave * enc_wave_dwords(a.stage_dw);
-    uint2 *lut = reinterpret_cast<uint2 *>(lds);
-    uint32_t *stage = lds + 32;
-    uint32_t *img = stage + a.stage_dw * 64;
-    const uint32_t ch = a.seg_ch[seg];
-    if (lane < kLut) lut[lane] = a.lut[(size_t)ch * kLut + lane];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint8_t *src = a.data + a.ch_off[ch] + a.w0[ch] + a.seg_first[seg];
-    const uint64_t n = a.seg_n[seg];
-    uint32_t *dst = a.payload + a.seg_off[seg];
-    uint64_t words = 0, bits = 0;
-    for (uint64_t q = 0; q < n; q += kChunk) {
-        const uint64_t left = n - q;
-        uint32_t w, b;
-        if (left >= (uint64_t)kChunk)
-            encode_chunk<FI, true>(src + q, kChunk, lut, stage, img, dst + words, lane, w, b);
-        else
-            encode_chunk<FI, false>(src + q, (uint32_t)left, lut, stage, img, dst + words, lane, w, b);
-        words += w;
-        bits += b;
-    }
-    if (lane == 0) {
-        a.seg_words[seg] = words;
-        atomicAdd(&a.ch_bits[ch], (unsigned long long)bits);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------
-struct DtabArgs {
-    const uint8_t *peak, *enc, *sclv;
-    const uint32_t *codes;
-    uint32_t C, S, mode;
-    uint8_t *dtab;  // C*512 : symbol | len << 4, indexed by the next maxlen stream bits
-    uint8_t *dlen;  // C : maxlen of the channel's encoder
-};
-
-__global__ __launch_bounds__(64) void k_build_dtab(DtabArgs a)
-{
-    const uint32_t ch = blockIdx.x;
-    const int S = (int)a.S, lane = threadIdx.x;
-    const int p = a.peak[ch];
-    const uint32_t k = a.enc[ch];
-    const int L = a.sclv[k * S + S - 1];  // rows are non-decreasing
-    if (lane == 0) a.dlen[ch] = (uint8_t)L;
-    for (int j = lane; j < (1 << L); j += 64) {
-        uint8_t e = 0;
-        for (int r = 0; r < S; ++r) {
-            const uint32_t c = a.codes[k * 16 + r];
-            const int len = (int)(c >> 16);
-            if ((uint32_t)(j & ((1 << len) - 1)) == (c & 0xFFFFu))
-                e = (uint8_t)(symbol_of_rank((int)a.mode, S, p, r) | (len << 4));
-        }
-        a.dtab[(size_t)ch * kDtab + j] = e;
-    }
-}
-
 struct DecArgs {
     const uint32_t *payload;
     const uint64_t *ch_off, *w0;
@@ -473,36 +311,6 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in
         }
     }
     return kHdrWords + ((B + 31) >> 5);
-}
-
-template <int FI>
-__global__ __launch_bounds__(256) void k_decode(DecArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t tabs[4][kDtab];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t seg = blockIdx.x * 4 + wave;
-    if (seg >= a.nseg) return;
-    const uint32_t ch = a.seg_ch[seg];
-    const int L = a.dlen[ch];
-    uint8_t *tab = tabs[wave];
-    {
-        const uint2 *g = reinterpret_cast<const uint2 *>(a.dtab + (size_t)ch * kDtab);
-        if (lane * 8 < (1 << L) || lane == 0) reinterpret_cast<uint2 *>(tab)[lane] = g[lane];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t mask = (1u << L) - 1u;
-    const uint32_t *in = a.payload + a.seg_off[seg];
-    uint8_t *out = a.out + a.ch_off[ch] + a.w0[ch] + a.seg_first[seg];
-    const uint64_t n = a.seg_n[seg];
-    uint64_t words = 0;
-    for (uint64_t q = 0; q < n; q += kChunk) {
-        const uint64_t left = n - q;
-        if (left >= (uint64_t)kChunk)
-            words += decode_chunk<FI, true>(in + words, kChunk, tab, mask, out + q, lane);
-        else
-            words += decode_chunk<FI, false>(in + words, (uint32_t)left, tab, mask, out + q, lane);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -598,28 +406,6 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *data, const uint64_t *ch
                 for (int i = 0; i < 16; ++i)
                     if (t0 + i < T) x[t0 + i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
             }
-        }
-    }
-}
-
-// out[b] = sum x[b*r .. min(b*r+r, T))  (functions_1.py:11-24 along time, per channel)
-template <bool SAT>
-__global__ __launch_bounds__(256) void k_rebin(const uint8_t *data, const uint64_t *in_off,
-                                               const uint64_t *in_len, uint32_t C, uint32_t r,
-                                               void *out, const uint64_t *out_off)
-{
-    for (uint32_t ch = blockIdx.y; ch < C; ch += gridDim.y) {
-        const uint64_t T = in_len[ch], nb = (T + r - 1) / r;
-        const uint8_t *x = data + in_off[ch];
-        for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < nb;
-             b += (uint64_t)gridDim.x * 256) {
-            const uint64_t t0 = b * r, t1 = t0 + r < T ? t0 + r : T;
-            uint32_t s = 0;
-            for (uint64_t t = t0; t < t1; ++t) s += x[t];
-            if (SAT)
-                reinterpret_cast<uint8_t *>(out)[out_off[ch] + b] = (uint8_t)(s > 255u ? 255u : s);
-            else
-                reinterpret_cast<uint32_t *>(out)[out_off[ch] + b] = s;
         }
     }
 }
