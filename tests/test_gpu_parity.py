@@ -372,3 +372,60 @@ def test_encode_decode_are_graph_capturable(mh, S):
         o = int(cs.ch_off[c])
         assert np.array_equal(got[o + 64:o + len(x)], np.minimum(x[64:], S - 1))
     plan.close()
+
+
+def test_randomised_design_points_vs_oracle(mh):
+    """60 random (S, h, mapper, window, K subset, seg_chunks, ragged lengths, byte offsets):
+    measure / encode / decode byte-exact against the CPU oracle."""
+    rng = np.random.RandomState(20261004)
+    tabs = helpers.sclv_tables()
+    for it in range(60):
+        S = int(rng.randint(2, 11))
+        h = int(rng.randint(0, 13))
+        mode, window = int(rng.randint(0, 2)), int(rng.randint(0, 4))
+        seg_chunks = int(rng.randint(1, 5))
+        rows = tabs[S]
+        keep = np.sort(rng.choice(len(rows), size=int(rng.randint(1, len(rows) + 1)), replace=False))
+        tab = rows[keep]
+        nch = int(rng.randint(1, 7))
+        lens = [int(rng.choice([1, 2, 17, 100, 4095, 16384, 16400, 33000, 50000, 70000])) + int(rng.randint(0, 40))
+                for _ in range(nch)]
+        chans = [np.minimum(rng.poisson(float(np.exp(rng.uniform(-3, 2.3))), size=T), 255).astype(np.uint8) for T in lens]
+        off = np.zeros(nch, np.uint64)
+        pos = int(rng.randint(0, 16))
+        for c, T in enumerate(lens):
+            off[c] = pos
+            pos += T + int(rng.randint(0, 23))
+        host = np.zeros(pos + 64, np.uint8)
+        for c, x in enumerate(chans):
+            host[int(off[c]):int(off[c]) + len(x)] = x
+        ln = np.array(lens, np.uint64)
+        data = torch.from_numpy(host).cuda()
+        plan = mh.codec.Plan(off, ln, S, h, mode, window, tab, seg_chunks=seg_chunks)
+        p = OC.Params(S, h, mode, window, tab, seg_chunks=seg_chunks)
+        tag = "iter %d S=%d h=%d mode=%d win=%d K=%d sc=%d lens=%s" % (it, S, h, mode, window, len(tab), seg_chunks, lens)
+        m, om = plan.measure(data), OC.measure(host, off, ln, p)
+        assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), om["bits"]), tag
+        assert np.array_equal(m.post_hist.cpu().numpy().astype(np.uint64), om["post_mapped"]), tag
+        assert np.array_equal(m.enc.cpu().numpy(), om["enc"]) and np.array_equal(m.peak.cpu().numpy(), om["peak"]), tag
+        e, oe = plan.encode(data), OC.encode(host, off, ln, p)
+        sw = e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments]
+        assert np.array_equal(sw, oe["seg_words"]), tag
+        assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), om["bits"]), tag
+        pay = e.payload.cpu().numpy().view(np.uint32)
+        seg = plan.segments()
+        for s_ in range(plan.n_segments):
+            o, n = int(seg["off"][s_]), int(sw[s_])
+            assert np.array_equal(pay[o:o + n], oe["payload"][o:o + n]), tag
+        out = torch.full_like(data, 0xAB)
+        plan.decode(e, out)
+        want = OC.decode(oe["payload"], off, ln, p, oe["peak"], oe["enc"], len(host))
+        got = out.cpu().numpy()
+        for c, T in enumerate(lens):
+            cc = min(2 ** h, T)
+            ee = cc + T // 2
+            w0, w1 = {0: ((cc, cc) if ee > T else (cc, ee)), 1: (cc, min(ee, T)), 2: (cc, T), 3: (0, T)}[window]
+            o = int(off[c])
+            assert np.array_equal(got[o + w0:o + w1], want[o + w0:o + w1]), tag
+            assert np.all(got[o:o + w0] == 0xAB) and np.all(got[o + w1:o + T] == 0xAB), tag
+        plan.close()
