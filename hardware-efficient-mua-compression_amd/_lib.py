@@ -43,6 +43,7 @@ PROTOTYPES = {
     "mh_plan_segments": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "mh_measure": (_int, [_vp] * 10),
     "mh_encode": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mh_encode_preset": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     "mh_decode": (_int, [_vp] * 7),
     "mh_compact": (_int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     "mh_synth_poisson": (_int, [_vp, _vp, _vp, _u32, _u64, _vp, _u64, _vp]),

@@ -119,11 +119,22 @@ class Plan:
                        self._z(max(self.n_segments, 1), torch.int64), self._z(C, torch.int64),
                        self._z(C, torch.uint8), self._z(C, torch.uint8), self._z(C, torch.uint8))
 
-    def encode(self, data, out=None):
+    def encode(self, data, out=None, preset=None):
+        """Calibrate + encode.  With preset=(peak, enc) (uint8 device tensors, one entry per
+        channel) the calibration is skipped and that word is used instead (mh_encode_preset):
+        the compression phase of a calibrate-then-stream protocol."""
         e = out or self.alloc_encoded()
-        _lib.check(_lib.lib().mh_encode(self._h, _ptr(data), _ptr(e.payload), e.payload.numel(),
-                                        _ptr(e.seg_words), _ptr(e.ch_bits), _ptr(e.peak), _ptr(e.enc),
-                                        _ptr(e.skipped), _stream()))
+        if preset is None:
+            _lib.check(_lib.lib().mh_encode(self._h, _ptr(data), _ptr(e.payload), e.payload.numel(),
+                                            _ptr(e.seg_words), _ptr(e.ch_bits), _ptr(e.peak), _ptr(e.enc),
+                                            _ptr(e.skipped), _stream()))
+        else:
+            peak, enc = preset
+            e.peak.copy_(peak)
+            e.enc.copy_(enc)
+            e.skipped.zero_()
+            _lib.check(_lib.lib().mh_encode_preset(self._h, _ptr(data), _ptr(e.peak), _ptr(e.enc), _ptr(e.payload),
+                                                   e.payload.numel(), _ptr(e.seg_words), _ptr(e.ch_bits), _stream()))
         return e
 
     def decode(self, enc, out):

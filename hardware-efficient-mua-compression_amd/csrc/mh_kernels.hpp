@@ -113,6 +113,31 @@ __global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
     }
 }
 
+// Encode LUTs from a PRESET per-channel (peak, encoder) word instead of a calibration pass: the
+// compression phase of the reference's RTL reads exactly this word from its RAM
+// (FPGA implementation/RAM.v:4, README.md:50-66).  16 lanes per channel.
+__global__ __launch_bounds__(256) void k_lut_preset(const uint8_t *peak, const uint8_t *enc,
+                                                    const uint32_t *codes, uint32_t C, uint32_t S,
+                                                    uint32_t mode, uint32_t K, uint2 *lut,
+                                                    unsigned long long *zero_bits, uint8_t *peak_out,
+                                                    uint8_t *enc_out)
+{
+    const uint32_t ch = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int v = threadIdx.x & 15;
+    if (ch >= C) return;
+    const int p = peak[ch] < S ? peak[ch] : 0;
+    const uint32_t k = enc[ch] < K ? enc[ch] : 0;
+    const int sym = v > (int)S - 1 ? (int)S - 1 : v;
+    const int r = rank_of_symbol((int)mode, (int)S, p, sym);
+    const uint32_t e = codes[k * 16 + r];
+    lut[(size_t)ch * kLut + v] = make_uint2(e & 0xFFFFu, e >> 16);
+    if (v == 0) {
+        if (zero_bits) zero_bits[ch] = 0;
+        if (peak_out) peak_out[ch] = (uint8_t)p;
+        if (enc_out) enc_out[ch] = (uint8_t)k;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // window histogram.  For symbols s = 0..S-2 count the bytes equal to s (the top bin is the
 // window length minus the rest, so no clip pass is needed).  Equality is tested on four

@@ -518,21 +518,9 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
     return MH_OK;
 }
 
-int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t payload_cap_words,
-              uint64_t *seg_words, uint64_t *ch_bits, uint8_t *peak, uint8_t *enc,
-              uint8_t *skipped, void *stream)
+static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t *seg_words,
+                         uint64_t *ch_bits, hipStream_t st)
 {
-    if (!p || !data || !payload || !seg_words || !ch_bits)
-        return fail(MH_ERR_ARG, "mh_encode: NULL argument");
-    if (payload_cap_words < p->info.payload_cap_words)
-        return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
-                    (unsigned long long)payload_cap_words,
-                    (unsigned long long)p->info.payload_cap_words);
-    hipStream_t st = (hipStream_t)stream;
-    uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
-    int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st, nullptr,
-                              reinterpret_cast<unsigned long long *>(ch_bits), skipped);
-    if (rc) return rc;
     if (p->info.n_segments == 0) return MH_OK;
     mh::EncArgs a;
     a.data = data;
@@ -554,6 +542,42 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
     a2.t.task_n = p->d_task_n;
     a2.t.ntask = p->n_tasks;
     return dispatch_encode(p, a2, st);
+}
+
+int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t payload_cap_words,
+              uint64_t *seg_words, uint64_t *ch_bits, uint8_t *peak, uint8_t *enc,
+              uint8_t *skipped, void *stream)
+{
+    if (!p || !data || !payload || !seg_words || !ch_bits)
+        return fail(MH_ERR_ARG, "mh_encode: NULL argument");
+    if (payload_cap_words < p->info.payload_cap_words)
+        return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
+                    (unsigned long long)payload_cap_words,
+                    (unsigned long long)p->info.payload_cap_words);
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
+    int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st, nullptr,
+                              reinterpret_cast<unsigned long long *>(ch_bits), skipped);
+    if (rc) return rc;
+    return encode_common(p, data, payload, seg_words, ch_bits, st);
+}
+
+int mh_encode_preset(mh_plan *p, const uint8_t *data, const uint8_t *peak, const uint8_t *enc,
+                     uint32_t *payload, uint64_t payload_cap_words, uint64_t *seg_words,
+                     uint64_t *ch_bits, void *stream)
+{
+    if (!p || !data || !peak || !enc || !payload || !seg_words || !ch_bits)
+        return fail(MH_ERR_ARG, "mh_encode_preset: NULL argument");
+    if (payload_cap_words < p->info.payload_cap_words)
+        return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
+                    (unsigned long long)payload_cap_words,
+                    (unsigned long long)p->info.payload_cap_words);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mh::k_lut_preset, dim3((p->info.C + 15) / 16), dim3(256), 0, st, peak, enc,
+                       (const uint32_t *)p->d_codes, p->info.C, p->info.S, p->info.mode, p->info.K, p->d_lut,
+                       reinterpret_cast<unsigned long long *>(ch_bits), (uint8_t *)nullptr, (uint8_t *)nullptr);
+    MH_HIP(hipGetLastError());
+    return encode_common(p, data, payload, seg_words, ch_bits, st);
 }
 
 int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, const uint8_t *peak,

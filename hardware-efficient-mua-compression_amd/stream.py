@@ -1,0 +1,62 @@
+"""Calibrate-then-stream use of the codec on implant-style data.
+
+The reference's RTL works in two phases (FPGA implementation/README.md:36-66): a CALIBRATION
+phase fills, per channel, a RAM word {most frequent spike rate, selected encoder}
+(RAM.v:4); in the COMPRESSION phase every later bin of every channel, arriving time-major
+|CH1|CH2|...|CHN| per time step (README.md:31), is mapped and encoded with that fixed word.
+`StreamEncoder` is the same protocol on the GPU: calibrate() on the first block, then
+encode_block() on each later block -- de-interleave (mh_deinterleave) + encode with the
+preset word (mh_encode_preset), no recalibration.
+"""
+import numpy as np
+import torch
+
+from . import MODE_APPROX, WIN_FULL, codec, container_io
+from .container import ChannelSet
+
+
+class StreamEncoder:
+    def __init__(self, C, S, hist_bits, sclv, mode=MODE_APPROX, seg_chunks=2, device="cuda"):
+        self.C, self.S, self.h, self.mode = int(C), int(S), int(hist_bits), int(mode)
+        self.sclv = np.ascontiguousarray(np.asarray(sclv, dtype=np.uint8).reshape(-1, self.S))
+        self.seg_chunks = int(seg_chunks)
+        self.device = torch.device(device, torch.cuda.current_device()) if device == "cuda" else torch.device(device)
+        self.peak = self.enc = None
+
+    def calibrate(self, block):
+        """block: [T0, C] time-major counts holding at least 2^hist_bits time steps (fewer are
+        accepted: the cutoff is min(2^h, T0), as functions_1.py:59-64).  Stores and returns the
+        per-channel RAM word (peak, enc) as uint8 device tensors."""
+        cs = ChannelSet.from_time_major(block, device=self.device)
+        plan = codec.Plan(cs.ch_off, cs.ch_len, self.S, self.h, self.mode, WIN_FULL, self.sclv)
+        m = plan.measure(cs.data)
+        torch.cuda.synchronize()
+        self.peak, self.enc = m.peak.clone(), m.enc.clone()
+        plan.close()
+        return self.peak, self.enc
+
+    def encode_block(self, block):
+        """block: [Tb, C] time-major counts -> container_io.Compressed covering all Tb bins of
+        every channel, coded with the stored RAM word."""
+        if self.peak is None:
+            raise RuntimeError("calibrate() first")
+        cs = ChannelSet.from_time_major(block, device=self.device)
+        plan = codec.Plan(cs.ch_off, cs.ch_len, self.S, 0, self.mode, WIN_FULL, self.sclv, seg_chunks=self.seg_chunks)
+        enc = plan.encode(cs.data, preset=(self.peak, self.enc))
+        dense, tot = plan.compact(enc)
+        torch.cuda.synchronize()
+        total = int(tot.item())
+        hdr = container_io.make_header(self.S, 0, self.mode, WIN_FULL, self.seg_chunks, self.sclv)
+        hdr["preset"] = True
+        c = container_io.Compressed(hdr, cs.ch_len.copy(), enc.peak.cpu().numpy(), enc.enc.cpu().numpy(),
+                                    enc.skipped.cpu().numpy(), enc.ch_bits.cpu().numpy().astype(np.uint64),
+                                    enc.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments],
+                                    dense.payload[:total].cpu().numpy().view(np.uint32).copy())
+        plan.close()
+        return c
+
+    @staticmethod
+    def decode_block(c, device="cuda"):
+        """-> [Tb, C] time-major array of min(x, S-1)."""
+        chans = container_io.decompress(c, device=device).to_channels()
+        return np.stack(chans, axis=1) if chans else np.zeros((0, 0), np.uint8)

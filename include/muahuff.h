@@ -135,6 +135,15 @@ int mh_encode(mh_plan *plan, const uint8_t *data, uint32_t *payload, uint64_t pa
               uint64_t *seg_words, uint64_t *ch_bits, uint8_t *peak, uint8_t *enc,
               uint8_t *skipped, void *stream);
 
+/* Compression phase of a calibrate-then-stream protocol: encode the plan's windows with a
+ * PRESET per-channel (peak, encoder) word instead of calibrating on this buffer -- what the
+ * reference's RTL does after its calibration phase, reading {max_rate, encoder_sel} from its RAM
+ * (FPGA implementation/README.md:50-66, RAM.v:4).  peak/enc: device, C entries (values out of
+ * range are treated as 0).  The stream decodes with mh_decode and the same peak/enc. */
+int mh_encode_preset(mh_plan *plan, const uint8_t *data, const uint8_t *peak, const uint8_t *enc,
+                     uint32_t *payload, uint64_t payload_cap_words, uint64_t *seg_words,
+                     uint64_t *ch_bits, void *stream);
+
 /* Inverse of mh_encode: writes clip(x) = min(x, S-1) for every window sample into `out`
  * (same channel layout as the plan's data buffer; bytes outside the windows are left
  * untouched).  seg_off (device, words) = where each segment starts in `payload`; NULL means

@@ -429,3 +429,36 @@ def test_randomised_design_points_vs_oracle(mh):
             assert np.array_equal(got[o + w0:o + w1], want[o + w0:o + w1]), tag
             assert np.all(got[o:o + w0] == 0xAB) and np.all(got[o + w1:o + T] == 0xAB), tag
         plan.close()
+
+
+def test_calibrate_then_stream_protocol(mh):
+    """Time-major blocks: calibrate on the first one, encode the following ones with the preset
+    (peak, encoder) word; each block round-trips and its bit count is the code-length sum under
+    that fixed word."""
+    from muahuff import stream
+    rng = np.random.RandomState(31)
+    C, S, h = 37, 5, 6
+    tab = helpers.sclv_tables()[S]
+    rates = np.exp(rng.uniform(np.log(0.05), np.log(3.0), size=C))
+    def block(T):
+        return np.minimum(rng.poisson(rates, size=(T, C)), 255).astype(np.uint8)
+    se = stream.StreamEncoder(C, S, h, tab)
+    first = block(64)
+    peak, enc = se.calibrate(first)
+    peak, enc = peak.cpu().numpy(), enc.cpu().numpy()
+    # the stored word equals what the oracle calibrates on the same 64 bins
+    p = OC.Params(S, h, 1, OC.WIN_FULL, tab)
+    data, off, ln = OC.flatten([first[:, c].copy() for c in range(C)])
+    om = OC.measure(data, off, ln, p)
+    assert np.array_equal(peak, om["peak"]) and np.array_equal(enc, om["enc"])
+    for T in (16384 * 2 + 100, 5000, 1):
+        x = block(T)
+        c = se.encode_block(x)
+        assert c.header["preset"] and np.array_equal(c.peak, peak) and np.array_equal(c.enc, enc)
+        back = stream.StreamEncoder.decode_block(c)
+        assert np.array_equal(back, np.minimum(x, S - 1))
+        for ch in range(C):
+            idx = OC.approx_sort_rule(S, int(peak[ch]))
+            rank_of = np.argsort(idx)
+            lens = tab[enc[ch]][rank_of[np.minimum(x[:, ch], S - 1)]]
+            assert int(c.ch_bits[ch]) == int(lens.sum()), ch
