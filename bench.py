@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-channels", type=int, default=96)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-deadline", type=int, default=90, help="seconds allowed for the untimed payload gather")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="round-trip check after the timed region")
@@ -82,6 +83,17 @@ def cpu_baseline(cs_host, ch_off, ch_len, S, h, mode, tab, seg_chunks, n_ch):
     t_np = time.perf_counter() - t0
     res["numpy_measure_msamples_s"] = (st["e"] - st["c"]) / t_np / 1e6
     return samples, res
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def pmc_traffic(kernel, C, T, S, h, seg_chunks):
@@ -186,17 +198,32 @@ def main():
     cb = words * 32 / samples          # container bits/sample (headers + padding included)
 
     gather = None
+    gather_hung = False
     if dist is not None and not a.no_gather:
+        # Untimed extra: concatenate the packed bitstreams on rank 0 (RCCL point-to-point over
+        # xGMI).  Run under a deadline in a helper thread so that a stuck collective can never
+        # cost the run its JSON line.
+        import threading
         from muahuff import dist as mdist
-        dense, tot = plan.compact(enc)
-        barrier()
-        g0 = time.perf_counter()
-        src = dense.payload if coll_dev == "cuda" else dense.payload.cpu()
-        pay, offs = mdist.gather_payload(src, int(tot.item()), dst=0)
-        barrier()
-        g = time.perf_counter() - g0
-        gather = dict(ms=g * 1e3, bytes_total=int(offs[-1]) * 4,
-                      GBps_into_root=(int(offs[-1]) - int(offs[1])) * 4 / g / 1e9)
+        box = {}
+
+        def do_gather():
+            torch.cuda.set_device(local)
+            dense, tot = plan.compact(enc)
+            barrier()
+            g0 = time.perf_counter()
+            src = dense.payload if coll_dev == "cuda" else dense.payload.cpu()
+            pay, offs = mdist.gather_payload(src, int(tot.item()), dst=0)
+            barrier()
+            g = time.perf_counter() - g0
+            box["v"] = dict(ms=g * 1e3, bytes_total=int(offs[-1]) * 4,
+                            GBps_into_root=(int(offs[-1]) - int(offs[1])) * 4 / g / 1e9)
+
+        th = threading.Thread(target=do_gather, daemon=True)
+        th.start()
+        th.join(a.gather_deadline)
+        gather_hung = th.is_alive()
+        gather = box.get("v") if not gather_hung else {"error": "gather did not finish within %ds" % a.gather_deadline}
 
     ok = None
     if a.verify:
@@ -255,8 +282,11 @@ def main():
                                               "oracle/mh_oracle.c encode+decode" % (nch, T, smp),
                                     "all_cores": res.get("all"), "single": res["1"],
                                     "numpy_measure_msamples_s": res["numpy_measure_msamples_s"],
-                                    "host_cpus": os.cpu_count()}
+                                    "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
         print(json.dumps(line), flush=True)
+    if gather_hung:
+        sys.stdout.flush()
+        os._exit(0)  # a collective is stuck: the line is out, leave without joining it
     if dist is not None:
         dist.destroy_process_group()
 
