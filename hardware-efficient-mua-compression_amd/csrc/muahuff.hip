@@ -74,12 +74,6 @@ int alloc(T **dst, size_t n)
     return MH_OK;
 }
 
-int flush_interval(uint32_t maxlen)
-{
-    // symbols between bit-buffer checks so that 31 + FI*maxlen <= 63
-    return maxlen <= 2 ? 16 : maxlen <= 4 ? 8 : maxlen <= 8 ? 4 : 3;
-}
-
 }  // namespace
 
 struct mh_plan {
