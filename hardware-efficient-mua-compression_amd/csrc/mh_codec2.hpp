@@ -675,7 +675,6 @@ __global__ __launch_bounds__(256) void k_hist2(HistArgs a, uint32_t S)
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
     const u32x4 *q = reinterpret_cast<const u32x4 *>(p + head);
     int pending = 0;
-#pragma unroll 2
     for (uint32_t i = tid; i < nvec; i += 256) {
         u32x4 x = __builtin_nontemporal_load(q + i);
         const uint32_t hi = (x.x | x.y | x.z | x.w) & kHiMask;
