@@ -16,6 +16,8 @@ __version__ = "0.1.0"
 
 def __getattr__(name):  # torch-dependent modules load lazily
     import importlib
-    if name in ("codec", "container", "container_io", "synth", "sweep", "stream", "analysis", "functions_1", "drivers", "dist"):
+    if name in ("bit_rates", "compress", "decompress"):
+        return getattr(importlib.import_module(".api", __name__), name)
+    if name in ("codec", "container", "container_io", "synth", "api", "sweep", "stream", "analysis", "functions_1", "drivers", "dist"):
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

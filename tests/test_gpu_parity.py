@@ -462,3 +462,22 @@ def test_calibrate_then_stream_protocol(mh):
             rank_of = np.argsort(idx)
             lens = tab[enc[ch]][rank_of[np.minimum(x[:, ch], S - 1)]]
             assert int(c.ch_bits[ch]) == int(lens.sum()), ch
+
+
+def test_package_level_api_matches_golden(mh, tmp_path):
+    """muahuff.bit_rates reproduces the reference's per-channel BRs of the golden fixture, and
+    muahuff.compress / decompress round-trip through a file."""
+    chans, recs = helpers.per_channel()
+    tabs = helpers.sclv_tables()
+    for x, r in list(zip(chans, recs))[::5]:
+        got = mh.bit_rates([x], S=r["S"], hist_bits=r["h"], approx=bool(r["approx"]), sclv_rows=tabs[r["S"]], BP=r["BP"])
+        want = float.fromhex(r["BR_hex"]) if r["BR_hex"] != "nan" else float("nan")
+        assert helpers.same_float(got["BR"][0], want)
+        assert int(got["enc"][0]) == r["enc"] and int(got["skipped"][0]) == r["skipped"]
+    rng = np.random.RandomState(2)
+    data = _channels(rng, [50000, 20000, 16384 + 64])
+    c = mh.compress(data, S=3, hist_bits=6, path=tmp_path / "a.mhf")
+    back = mh.decompress(tmp_path / "a.mhf")
+    for x, y in zip(data, back):
+        assert np.array_equal(y[64:], np.minimum(x[64:], 2))
+    assert c.payload_bits == int(sum(c.ch_bits))
