@@ -510,16 +510,16 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
                                                     int lane)
 {
-    uint32_t wi = h.P >> 5, bp = h.P & 31;
+    // Bit window: 64 bits starting at word `wi` of the staged payload, `bp` bits already used.
+    // K >= 2 (few lookups per lane): every M lookups the window is simply RE-READ from LDS at the
+    //   lane's absolute bit position -- branch-free; a conditional refill would run for the whole
+    //   wave almost every step because some lane always needs one (S=3 decode 2.29 -> 2.11 ms).
+    // K == 1 (256 dependent lookups per lane): the extra LDS read in the chain costs more than the
+    //   divergent branch, so the window is shifted and topped up from a one-word read-ahead.
+    constexpr bool kReload = K >= 2;
+    uint32_t pos = h.P, wi = h.P >> 5, bp = h.P & 31;
     uint64_t buf = (uint64_t)stage[wi] | ((uint64_t)stage[wi + 1] << 32);
-    uint32_t nxt = stage[wi + 2];
-#define MH_REFILL()                                  \
-    if (bp >= 32) {                                  \
-        buf = (buf >> 32) | ((uint64_t)nxt << 32);   \
-        bp -= 32;                                    \
-        ++wi;                                        \
-        nxt = stage[wi + 2];                         \
-    }
+    uint32_t nxt = kReload ? 0u : stage[wi + 2];
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         u32x4 o;
@@ -529,22 +529,35 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
 #pragma unroll
             for (int i = 0; i < 4 / K; ++i) {
                 const uint32_t idx = (uint32_t)(buf >> bp) & maskW;
+                uint32_t adv;
                 if (K == 4) {
                     const uint2 e = reinterpret_cast<const uint2 *>(tabw)[idx];
                     w = e.x;
-                    bp += e.y;
+                    adv = e.y;
                 } else {
                     const uint32_t e = tabw[idx];
                     w |= (e & 0xFFFFu) << (8 * K * i);
-                    bp += e >> 16;
+                    adv = e >> 16;
                 }
-                if ((d * (4 / K) + i + 1) % M == 0) { MH_REFILL(); }
+                bp += adv;
+                if (kReload) pos += adv;
+                if ((d * (4 / K) + i + 1) % M == 0) {
+                    if (kReload) {
+                        const uint32_t w_ = pos >> 5;
+                        buf = (uint64_t)stage[w_] | ((uint64_t)stage[w_ + 1] << 32);
+                        bp = pos & 31;
+                    } else if (bp >= 32) {
+                        buf = (buf >> 32) | ((uint64_t)nxt << 32);
+                        bp -= 32;
+                        ++wi;
+                        nxt = stage[wi + 2];
+                    }
+                }
             }
             o[d] = w;
         }
         __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + ((uint32_t)k * kLanes + lane) * MH_PIECE));
     }
-#undef MH_REFILL
 }
 
 // NR payload registers per lane: the next chunk's payload (up to NR*64 words) is fetched into
