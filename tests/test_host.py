@@ -146,3 +146,14 @@ def test_design_point_table_matches_reference_formula():
     a = np.mean([np.mean(z["approx/S2_BP10_CV%d/BRs" % cv][0][0]) for cv in (1, 2)])
     assert tab[0, :4].tolist() == [10, 2, 2, 1] and helpers.same_float(tab[0, 4], a)
     assert tab.shape[1] == 6 and tab.shape[0] == 2 * 94 * 9
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No libmuahuff.so -> ImportError at first use, never a silent CPU path."""
+    import subprocess
+    import sys
+    code = ("import muahuff\n"
+            "try:\n    muahuff._lib.lib()\nexcept ImportError as e:\n    print('LOUD', 'no CPU fallback' in str(e))\n")
+    env = dict(os.environ, MUAHUFF_LIB=str(tmp_path / "nope.so"), PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "LOUD True" in out.stdout, out.stdout + out.stderr
