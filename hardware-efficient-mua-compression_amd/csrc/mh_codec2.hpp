@@ -22,8 +22,6 @@ struct TaskArgs {
     const uint32_t *task_seg0;  // first segment of the task
     const uint8_t *task_n;      // segments in the task (1..4), all of one channel
     uint32_t ntask;
-    uint32_t per_wg;            // consecutive tasks one workgroup walks (tables rebuilt only when
-                                // the channel changes)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -360,67 +358,59 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x;
+    const uint32_t seg0 = a.t.task_seg0[task];
+    const uint32_t nseg = a.t.task_n[task];
+    const uint32_t ch = a.e.seg_ch[seg0];
     uint2 *lut2 = reinterpret_cast<uint2 *>(smem);
     uint2 *lut1 = reinterpret_cast<uint2 *>(smem + 512);
+    {   // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
+        const uint2 *g = a.e.lut + (size_t)ch * kLut;
+        const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
+        if (threadIdx.x < (1u << (2 * PB))) {
+            const uint2 ea = g[b0], eb = g[b1];
+            uint32_t idx = b0 | (b1 << PB);
+            if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
+            lut2[idx] = make_uint2(ea.x | (eb.x << ea.y), ea.y + eb.y);
+        }
+        if (threadIdx.x < kLut) lut1[threadIdx.x] = g[threadIdx.x];
+    }
+    __syncthreads();
+    if ((uint32_t)wave >= nseg) return;
+    const uint32_t seg = seg0 + wave;
     const uint32_t cap = a.e.stage_dw;
     uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
-    const uint32_t t_begin = blockIdx.x * a.t.per_wg;
-    const uint32_t t_end = t_begin + a.t.per_wg < a.t.ntask ? t_begin + a.t.per_wg : a.t.ntask;
-    uint32_t cur_ch = 0xFFFFFFFFu;
-    for (uint32_t task = t_begin; task < t_end; ++task) {
-        const uint32_t seg0 = a.t.task_seg0[task];
-        const uint32_t nseg = a.t.task_n[task];
-        const uint32_t ch = a.e.seg_ch[seg0];
-        if (ch != cur_ch) {  // workgroup-uniform: (re)build this channel's tables
-            __syncthreads();
-            // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
-            const uint2 *g = a.e.lut + (size_t)ch * kLut;
-            const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
-            if (threadIdx.x < (1u << (2 * PB))) {
-                const uint2 ea = g[b0], eb = g[b1];
-                uint32_t idx = b0 | (b1 << PB);
-                if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
-                lut2[idx] = make_uint2(ea.x | (eb.x << ea.y), ea.y + eb.y);
-            }
-            if (threadIdx.x < kLut) lut1[threadIdx.x] = g[threadIdx.x];
-            __syncthreads();
-            cur_ch = ch;
-        }
-        if ((uint32_t)wave >= nseg) continue;
-        const uint32_t seg = seg0 + wave;
-        const uint8_t *src = a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg];
-        const uint64_t n = a.e.seg_n[seg];
-        uint32_t *__restrict__ out = a.e.payload + a.e.seg_off[seg];  // next unflushed word
-        uint32_t pend = 0;                                            // words waiting in LDS behind `out`
-        const uint32_t nfull = (uint32_t)(n / kChunk);
-        const uint32_t rem = (uint32_t)(n % kChunk);
-        uint64_t words = 0, bits = 0;
-        if (nfull) {
-            u32x4 v[kWin];
+    const uint8_t *src = a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg];
+    const uint64_t n = a.e.seg_n[seg];
+    uint32_t *__restrict__ out = a.e.payload + a.e.seg_off[seg];  // next unflushed word
+    uint32_t pend = 0;                                            // words waiting in LDS behind `out`
+    const uint32_t nfull = (uint32_t)(n / kChunk);
+    const uint32_t rem = (uint32_t)(n % kChunk);
+    uint64_t words = 0, bits = 0;
+    if (nfull) {
+        u32x4 v[kWin];
 #pragma unroll
-            for (int k = 0; k < kWin; ++k) v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
-            for (uint32_t c = 0; c < nfull; ++c) {
-                uint32_t w, b;
-                encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, lut1, buf, cap,
-                                               out, pend, lane, w, b);
-                words += w;
-                bits += b;
-            }
+        for (int k = 0; k < kWin; ++k) v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
+        for (uint32_t c = 0; c < nfull; ++c) {
+            uint32_t w, b;
+            encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, lut1, buf, cap,
+                                           out, pend, lane, w, b);
+            words += w;
+            bits += b;
         }
-        if (rem) {
-            const uint4 r = encode_partial_chunk<(LC == 0 ? 4 : 8)>(src + (size_t)nfull * kChunk, rem, lut1, buf,
-                                                                     cap, out, pend, lane);
-            words += r.x;
-            bits += r.y;
-            pend = r.z;
-            out += r.w;
-        }
-        if (ABL < 1 && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
-        MH_WAVE_SYNC();
-        if (lane == 0) {
-            a.e.seg_words[seg] = words;
-            atomicAdd(&a.e.ch_bits[ch], (unsigned long long)bits);
-        }
+    }
+    if (rem) {
+        const uint4 r = encode_partial_chunk<(LC == 0 ? 4 : 8)>(src + (size_t)nfull * kChunk, rem, lut1, buf, cap,
+                                                                 out, pend, lane);
+        words += r.x;
+        bits += r.y;
+        pend = r.z;
+        out += r.w;
+    }
+    if (ABL < 1 && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
+    if (lane == 0) {
+        a.e.seg_words[seg] = words;
+        atomicAdd(&a.e.ch_bits[ch], (unsigned long long)bits);
     }
 }
 
@@ -581,76 +571,71 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x;
+    const uint32_t seg0 = a.t.task_seg0[task];
+    const uint32_t nseg = a.t.task_n[task];
+    const uint32_t ch = a.d.seg_ch[seg0];
     const uint32_t W = a.W;
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
-    constexpr uint32_t kCap = NR * 64;
     uint32_t *tab = smem;
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (kEntDw << W));
+    {
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(a.dtab2) + (((size_t)ch << W) * kEntDw);
+        for (uint32_t i = threadIdx.x; i < (kEntDw << W); i += 256) tab[i] = g[i];
+        if (threadIdx.x < kDtab / 8)
+            reinterpret_cast<uint2 *>(tab1)[threadIdx.x] =
+                reinterpret_cast<const uint2 *>(a.d.dtab + (size_t)ch * kDtab)[threadIdx.x];
+    }
+    __syncthreads();
+    if ((uint32_t)wave >= nseg) return;
+    const uint32_t seg = seg0 + wave;
+    constexpr uint32_t kCap = NR * 64;
     uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * kCap;
     const uint32_t maskW = (1u << W) - 1u;
-    const uint32_t t_begin = blockIdx.x * a.t.per_wg;
-    const uint32_t t_end = t_begin + a.t.per_wg < a.t.ntask ? t_begin + a.t.per_wg : a.t.ntask;
-    uint32_t cur_ch = 0xFFFFFFFFu;
-    for (uint32_t task = t_begin; task < t_end; ++task) {
-        const uint32_t seg0 = a.t.task_seg0[task];
-        const uint32_t nseg = a.t.task_n[task];
-        const uint32_t ch = a.d.seg_ch[seg0];
-        if (ch != cur_ch) {  // workgroup-uniform: load this channel's tables
-            __syncthreads();
-            const uint32_t *g = reinterpret_cast<const uint32_t *>(a.dtab2) + (((size_t)ch << W) * kEntDw);
-            for (uint32_t i = threadIdx.x; i < (kEntDw << W); i += 256) tab[i] = g[i];
-            if (threadIdx.x < kDtab / 8)
-                reinterpret_cast<uint2 *>(tab1)[threadIdx.x] =
-                    reinterpret_cast<const uint2 *>(a.d.dtab + (size_t)ch * kDtab)[threadIdx.x];
-            __syncthreads();
-            cur_ch = ch;
-        }
-        if ((uint32_t)wave >= nseg) continue;
-        const uint32_t seg = seg0 + wave;
-        const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
-        const uint32_t *in = a.d.payload + a.d.seg_off[seg];
-        uint8_t *out = a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg];
-        const uint64_t n = a.d.seg_n[seg];
-        const uint32_t nfull = (uint32_t)(n / kChunk);
-        const uint32_t rem = (uint32_t)(n % kChunk);
-        if (nfull) {
-            uint32_t R[NR];
-            ChunkHdr cur = scan_header(in[lane >> 1], lane);
-            const uint32_t *pay = in + kHdrWords;
-            uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
+    const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
+    const uint32_t *in = a.d.payload + a.d.seg_off[seg];
+    uint8_t *out = a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg];
+    const uint64_t n = a.d.seg_n[seg];
+    const uint32_t nfull = (uint32_t)(n / kChunk);
+    const uint32_t rem = (uint32_t)(n % kChunk);
+    if (nfull) {
+        uint32_t R[NR];
+        ChunkHdr cur = scan_header(in[lane >> 1], lane);
+        const uint32_t *pay = in + kHdrWords;
+        uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
 #pragma unroll
-            for (int j = 0; j < NR; ++j)
-                if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];  // reads <= 3 words of slack
-            uint32_t hw_next = 0;
-            if (nfull > 1) hw_next = pay[cur.nw + (lane >> 1)];
-            for (uint32_t c = 0; c < nfull; ++c) {
+        for (int j = 0; j < NR; ++j)
+            if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];  // reads <= 3 words of slack
+        uint32_t hw_next = 0;
+        if (nfull > 1) hw_next = pay[cur.nw + (lane >> 1)];
+        for (uint32_t c = 0; c < nfull; ++c) {
 #pragma unroll
-                for (int j = 0; j < NR; ++j)  // payload(c): registers -> LDS
-                    if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
-                const ChunkHdr hc = cur;
-                const uint32_t *pay_c = pay;
-                const bool staged = ns != 0;
-                MH_WAVE_SYNC();
-                if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
-                    pay = pay + cur.nw + kHdrWords;
-                    cur = scan_header(hw_next, lane);
-                    ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
+            for (int j = 0; j < NR; ++j)  // payload(c): registers -> LDS
+                if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
+            const ChunkHdr hc = cur;
+            const uint32_t *pay_c = pay;
+            const bool staged = ns != 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
+                pay = pay + cur.nw + kHdrWords;
+                cur = scan_header(hw_next, lane);
+                ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
 #pragma unroll
-                    for (int j = 0; j < NR; ++j)
-                        if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];
-                    if (c + 2 < nfull) hw_next = pay[cur.nw + (lane >> 1)];
-                }
-                if (staged)
-                    decode_staged_chunk<K, M>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
-                else
-                    decode_chunk<3, true>(pay_c - kHdrWords, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
-                MH_WAVE_SYNC();
+                for (int j = 0; j < NR; ++j)
+                    if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];
+                if (c + 2 < nfull) hw_next = pay[cur.nw + (lane >> 1)];
             }
-            in = pay + cur.nw;  // first word after the last full chunk
+            if (staged)
+                decode_staged_chunk<K, M>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
+            else
+                decode_chunk<3, true>(pay_c - kHdrWords, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        if (rem) decode_chunk<3, false>(in, rem, tab1, mask1, out + (size_t)nfull * kChunk, lane);
-        MH_WAVE_SYNC();
+        in = pay + cur.nw;  // first word after the last full chunk
     }
+    if (rem) decode_chunk<3, false>(in, rem, tab1, mask1, out + (size_t)nfull * kChunk, lane);
 }
 
 // ------------------------------------------------------------------------------------------

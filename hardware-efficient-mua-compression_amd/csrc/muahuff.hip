@@ -5,7 +5,6 @@
 
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -151,17 +150,6 @@ static void launch_hist(const mh::HistArgs &a, uint64_t n_tiles, hipStream_t st)
 
 int g_ablate = 0;  // debug only (mhdbg_set_ablation); 0 in production
 
-// consecutive tasks (4 segments each) one workgroup walks; MH_TASKS_PER_WG overrides for tuning
-static uint32_t tasks_per_wg()
-{
-    static const uint32_t v = [] {
-        const char *e = getenv("MH_TASKS_PER_WG");
-        const long n = e ? strtol(e, nullptr, 10) : 0;
-        return (uint32_t)(n >= 1 && n <= 1024 ? n : 1);
-    }();
-    return v;
-}
-
 // The launch helpers double as "prepare" helpers: with this thread-local flag set they only
 // raise the kernel's dynamic-LDS limit (hipFuncSetAttribute) and do not launch.  mh_plan_create
 // runs them once that way, so mh_encode / mh_decode issue nothing but stream work and stay
@@ -175,7 +163,7 @@ static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
     const size_t lds = ((size_t)mh::kEncSharedDw + 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw)) * sizeof(uint32_t);
     auto kern = mh::k_encode2<LC, PB, ABL>;
     if (!st_prepare_only_flag()) {
-        hipLaunchKernelGGL(kern, dim3((a.t.ntask + a.t.per_wg - 1) / a.t.per_wg), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     } else if (lds > 64 * 1024) {  // plan creation: raise the dynamic-LDS limit once, outside any capture
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -193,7 +181,7 @@ static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
     const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
     auto kern = mh::k_decode2<K, M, NR>;
     if (!st_prepare_only_flag()) {
-        hipLaunchKernelGGL(kern, dim3((a.t.ntask + a.t.per_wg - 1) / a.t.per_wg), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     } else if (lds > 64 * 1024) {
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -547,7 +535,6 @@ static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uin
     a2.t.task_seg0 = p->d_task_seg0;
     a2.t.task_n = p->d_task_n;
     a2.t.ntask = p->n_tasks;
-    a2.t.per_wg = tasks_per_wg();
     return dispatch_encode(p, a2, st);
 }
 
@@ -625,7 +612,6 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
     a2.t.task_seg0 = p->d_task_seg0;
     a2.t.task_n = p->d_task_n;
     a2.t.ntask = p->n_tasks;
-    a2.t.per_wg = tasks_per_wg();
     a2.dtab2 = p->d_dtab2;
     a2.W = p->W;
     return dispatch_decode(p, a2, st);
