@@ -505,18 +505,19 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw, int lane)
 // K symbols per table lookup (4, 2 or 1), bit buffer topped up every M lookups (M * W <= 33).
 // The loop issues no global load, so nothing in it waits on the vector-memory counter (which
 // also counts the 16-byte output stores).
-template <int K, int M>
+template <int K, int M, bool RL>
 __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *tabw, uint32_t maskW,
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
                                                     int lane)
 {
     // Bit window: 64 bits starting at word `wi` of the staged payload, `bp` bits already used.
-    // K >= 2 (few lookups per lane): every M lookups the window is simply RE-READ from LDS at the
-    //   lane's absolute bit position -- branch-free; a conditional refill would run for the whole
-    //   wave almost every step because some lane always needs one (S=3 decode 2.29 -> 2.11 ms).
-    // K == 1 (256 dependent lookups per lane): the extra LDS read in the chain costs more than the
-    //   divergent branch, so the window is shifted and topped up from a one-word read-ahead.
-    constexpr bool kReload = K >= 2;
+    // RL (reload): every M lookups the window is simply RE-READ from LDS at the lane's absolute bit
+    //   position -- branch-free; a conditional refill runs for the whole wave almost every step
+    //   because some lane always needs one (S=3 decode 2.29 -> 2.11 ms).
+    // !RL: the window is shifted and topped up from a one-word read-ahead when 32 bits are used
+    //   up; better where the extra LDS read in the dependent chain costs more than the divergent
+    //   branch (chosen per variant by measurement, see dispatch_decode).
+    constexpr bool kReload = RL;
     uint32_t pos = h.P, wi = h.P >> 5, bp = h.P & 31;
     uint64_t buf = (uint64_t)stage[wi] | ((uint64_t)stage[wi + 1] << 32);
     uint32_t nxt = kReload ? 0u : stage[wi + 2];
@@ -566,7 +567,7 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
 // (in-order vmcnt) never waits for a store.  A chunk whose payload exceeds NR*64 words (more
 // than 3 bits/sample when NR = 24; impossible when NR = 17 and maxlen <= 2) takes the
 // per-symbol routine that reads the stream straight from global memory.
-template <int K, int M, int NR>
+template <int K, int M, int NR, bool RL>
 __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
                 if (c + 2 < nfull) hw_next = pay[cur.nw + (lane >> 1)];
             }
             if (staged)
-                decode_staged_chunk<K, M>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
+                decode_staged_chunk<K, M, RL>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
             else
                 decode_chunk<3, true>(pay_c - kHdrWords, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

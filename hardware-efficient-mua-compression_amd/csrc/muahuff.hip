@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -175,11 +176,11 @@ static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
     return MH_OK;
 }
 
-template <int K, int M, int NR>
+template <int K, int M, int NR, bool RL>
 static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
 {
     const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
-    auto kern = mh::k_decode2<K, M, NR>;
+    auto kern = mh::k_decode2<K, M, NR, RL>;
     if (!st_prepare_only_flag()) {
         hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     } else if (lds > 64 * 1024) {
@@ -219,10 +220,12 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
 static int dispatch_decode(const mh_plan *p, const mh::Dec2Args &a2, hipStream_t st)
 {
     const uint32_t L = p->info.maxlen;
-    if (L <= 2) return launch_decode2<4, 4, 17>(a2, st);  // worst-case chunk = 1027 words: never oversize
-    if (L == 3) return launch_decode2<2, 2, 25>(a2, st);  // worst case 1539 words: never oversize
-    if (L <= 6) return launch_decode2<2, 2, 32>(a2, st);  // staged up to 4 bits/sample
-    return launch_decode2<1, 2, 32>(a2, st);
+    static const int force = [] { const char *e = getenv("MH_DEC_RELOAD"); return e ? atoi(e) : -1; }();  // tuning only
+    if (L <= 2) return launch_decode2<4, 4, 17, true>(a2, st);  // worst-case chunk = 1027 words: never oversize
+    const bool rl = force >= 0 ? force != 0 : false;            // measured: reload only pays for K = 4 (profiles/README.md)
+    if (L == 3) return rl ? launch_decode2<2, 2, 25, true>(a2, st) : launch_decode2<2, 2, 25, false>(a2, st);
+    if (L <= 6) return rl ? launch_decode2<2, 2, 32, true>(a2, st) : launch_decode2<2, 2, 32, false>(a2, st);
+    return launch_decode2<1, 2, 32, false>(a2, st);
 }
 
 // raise the dynamic-LDS limits of the kernels this plan will launch (once, at plan creation)
