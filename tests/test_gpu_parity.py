@@ -481,3 +481,29 @@ def test_package_level_api_matches_golden(mh, tmp_path):
     for x, y in zip(data, back):
         assert np.array_equal(y[64:], np.minimum(x[64:], 2))
     assert c.payload_bits == int(sum(c.ch_bits))
+
+
+def test_many_channels_and_extreme_parameters(mh):
+    """70 000 tiny channels (grid-dimension limits), h far beyond the channel length, K = 35."""
+    rng = np.random.RandomState(77)
+    C = 70000
+    lens = rng.randint(1, 400, size=C)
+    chans = [rng.randint(0, 11, size=int(T)).astype(np.uint8) for T in lens]
+    cs = _cs(mh, chans)
+    S, tab = 10, helpers.sclv_tables()[10]
+    for h, window in ((30, mh.WIN_FULL), (3, mh.WIN_REF_HALF)):
+        plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, 1, window, tab)
+        p = OC.Params(S, h, 1, window, tab)
+        host = cs.data.cpu().numpy()
+        m = plan.measure(cs.data)
+        om = OC.measure(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+        assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), om["bits"])
+        assert np.array_equal(m.enc.cpu().numpy(), om["enc"]) and np.array_equal(m.skipped.cpu().numpy(), om["skipped"])
+        e = plan.encode(cs.data)
+        assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), om["bits"])
+        out = torch.zeros_like(cs.data)
+        plan.decode(e, out)
+        oe = OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+        want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host), nthreads=8)
+        assert np.array_equal(out.cpu().numpy(), want)
+        plan.close()
