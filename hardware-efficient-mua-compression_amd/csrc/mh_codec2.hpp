@@ -88,7 +88,8 @@ __device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src,
 }
 
 // LC: 0 maxlen<=2 (flush check per piece), 1 maxlen<=4 (per 2 dwords), 2 maxlen<=8 (per dword),
-//     3 maxlen==9 (per pair, no 32-bit quad merge)
+//     3 maxlen==9 (as 2, with a wave-uniform escape to per-pair flushing when four codewords
+//       exceed 32 bits)
 // PB: bits per symbol in the pair index.  PB=3 (S<=8) keeps the hot entries (small symbols) on
 //     distinct LDS banks; PB=4 (S=9,10) xor-swizzles the index for the same reason.
 constexpr int kWin = 8;  // rows (1 KiB each) a wave keeps in flight
@@ -261,7 +262,9 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
             const uint32_t y = pair_index_word<PB>(x[d]);
             const uint2 e0 = lut2[y & 0xFFu];
             const uint2 e1 = lut2[(y >> 16) & 0xFFu];
-            if (LC == 3) {
+            if (LC == 3 && __builtin_expect(__any(e0.y + e1.y > 32u), 0)) {
+                // four codewords longer than a dword somewhere in the wave (needs four symbols
+                // of rank >= 7 in a row): pair by pair
                 acc |= (uint64_t)e0.x << nb;
                 nb += e0.y;
                 MH_FLUSH();
@@ -272,7 +275,7 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
                 const uint32_t q = e0.x | (e1.x << e0.y);
                 acc |= (uint64_t)q << nb;
                 nb += e0.y + e1.y;
-                if (LC == 2 || (LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
+                if (LC >= 2 || (LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
             }
         }
     }
@@ -421,14 +424,14 @@ struct Dtab2Args {
     const uint8_t *peak, *enc, *sclv;
     const uint32_t *codes;
     uint32_t C, S, mode, W, K;
-    void *dtab2;  // C << W entries: K == 4 -> uint2 {4 symbol bytes, bits consumed};
-                  // K <= 2 -> u32 (symbol bytes in the low half, bits consumed in the high half)
+    void *dtab2;  // K == 4 plans only: C << W entries uint2 {4 symbol bytes, bits consumed}
     uint8_t *dtab;  // C*512 per-symbol table: symbol | len << 4, indexed by the next maxlen bits
     uint8_t *dlen;  // C : max code length of the channel's encoder
 };
 
-// Entry idx = the next W stream bits; it decodes exactly K symbols (W >= K * maxlen, and the
-// code is complete, so K codewords always fit) -> {symbols spread to bytes, total length}.
+// Per-symbol table of every channel, and for K == 4 plans (maxlen <= 2) the 4-symbol table:
+// entry idx = the next W = 8 stream bits, which always hold 4 whole codewords of a complete code
+// -> {symbols spread to bytes, total length}.
 __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
 {
     const uint32_t ch = blockIdx.x;
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
             a.dtab[(size_t)ch * kDtab + j] = e;
         }
     }
+    if (K != 4) return;  // pair tables (K == 2) are derived inside k_decode2 from the per-symbol table
     for (uint32_t idx = threadIdx.x; idx < (1u << W); idx += 256) {
         uint32_t pos = 0, bytes = 0;
         for (int j = 0; j < K; ++j) {
@@ -464,10 +468,7 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
             bytes |= sym[hit] << (8 * j);
             pos += clen[hit];
         }
-        if (K == 4)
-            reinterpret_cast<uint2 *>(a.dtab2)[((size_t)ch << W) + idx] = make_uint2(bytes, pos);
-        else
-            reinterpret_cast<uint32_t *>(a.dtab2)[((size_t)ch << W) + idx] = bytes | (pos << 16);
+        reinterpret_cast<uint2 *>(a.dtab2)[((size_t)ch << W) + idx] = make_uint2(bytes, pos);
     }
 }
 
@@ -479,7 +480,7 @@ struct Dec2Args {
 };
 
 // LDS dwords of the workgroup-shared tables: multi-symbol table (2 dwords per entry for K = 4,
-// 1 otherwise) + the 512-byte per-symbol table used by partial / oversize chunks
+// 1 for the pair table) + the 512-byte per-symbol table used by partial / oversize chunks
 __host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W, uint32_t K)
 {
     return ((K == 4 ? 2u : 1u) << W) + kDtab / 4;
@@ -502,11 +503,15 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw, int lane)
 }
 
 // Decodes one full chunk whose whole payload (+3 words of read-ahead) sits in LDS `stage`.
-// K symbols per table lookup (4, 2 or 1), bit buffer topped up every M lookups (M * W <= 33).
+// K symbols per table lookup (4 or 2), bit buffer topped up every M lookups.
 // The loop issues no global load, so nothing in it waits on the vector-memory counter (which
 // also counts the 16-byte output stores).
-template <int K, int M, bool RL>
+// HY (hybrid pair table, maxlen > W/2): an entry whose second codeword does not fit in the W
+// index bits has bit 31 set and carries one symbol; the second comes from the per-symbol table
+// `tab1` in a branch that whole waves skip (long codewords belong to rare symbols).
+template <int K, int M, int RL, bool HY>
 __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *tabw, uint32_t maskW,
+                                                    const uint8_t *tab1, uint32_t mask1,
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
                                                     int lane)
 {
@@ -514,11 +519,27 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
     // RL (reload): every M lookups the window is simply RE-READ from LDS at the lane's absolute bit
     //   position -- branch-free; a conditional refill runs for the whole wave almost every step
     //   because some lane always needs one (S=3 decode 2.29 -> 2.11 ms).
-    // !RL: the window is shifted and topped up from a one-word read-ahead when 32 bits are used
-    //   up; better where the extra LDS read in the dependent chain costs more than the divergent
-    //   branch (chosen per variant by measurement, see dispatch_decode).
-    constexpr bool kReload = RL;
-    uint32_t pos = h.P, wi = h.P >> 5, bp = h.P & 31;
+    // RL == 0: the window is shifted and topped up from a one-word read-ahead when 32 bits are
+    //   used up; better where the extra LDS read in the dependent chain costs more than the
+    //   divergent branch (chosen per variant by measurement, see dispatch_decode).
+    // RL == 2: the same top-up written with selects instead of a branch (the read-ahead word is
+    //   re-read every time, off the dependent chain).
+    // Window bound (!RL, HY, M = 2, W <= 12, maxlen <= 9): bp < 32 after a top-up; a pair lookup
+    //   needs bp + SH + W <= 64 and advances <= W, the flagged branch tops up first and advances
+    //   <= 9, so bp stays below 56 and one top-up always restores bp < 32.
+    static_assert(!HY || (K == 2 && RL != 1), "hybrid entries exist for the pair table only");
+    // Pre-scaled index: the window is kept SH bits "early" (bp = stream position - SH, counted
+    //   from the word before the staged payload), so (window >> bp) & (mask << SH) is already the
+    //   byte offset of the table entry -- no shift in the lookup's dependent chain.  The table
+    //   sits at LDS address 0, so the offset is the address.  Pair tables only: with K = 4 the
+    //   last of the 4 lookups between reloads may start at window bit 55 and needs 8 more, which
+    //   leaves no room for scale bits.
+    constexpr bool kReload = RL == 1;
+    constexpr uint32_t SH = K == 4 ? 0 : 2;  // log2(bytes per pair-table entry)
+    typedef const __attribute__((address_space(3))) uint32_t lds_u1;
+    const uint32_t maskS = maskW << SH;
+    stage -= 1;
+    uint32_t pos = h.P + 32 - SH, wi = pos >> 5, bp = pos & 31;
     uint64_t buf = (uint64_t)stage[wi] | ((uint64_t)stage[wi + 1] << 32);
     uint32_t nxt = kReload ? 0u : stage[wi + 2];
 #pragma unroll
@@ -529,16 +550,28 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
             uint32_t w = 0;
 #pragma unroll
             for (int i = 0; i < 4 / K; ++i) {
-                const uint32_t idx = (uint32_t)(buf >> bp) & maskW;
+                const uint32_t off = (uint32_t)(buf >> bp) & maskS;
                 uint32_t adv;
                 if (K == 4) {
-                    const uint2 e = reinterpret_cast<const uint2 *>(tabw)[idx];
+                    const uint2 e = reinterpret_cast<const uint2 *>(tabw)[off];
                     w = e.x;
                     adv = e.y;
                 } else {
-                    const uint32_t e = tabw[idx];
+                    const uint32_t e = *reinterpret_cast<lds_u1 *>(off);
                     w |= (e & 0xFFFFu) << (8 * K * i);
-                    adv = e >> 16;
+                    adv = HY ? (e >> 16) & 0x7FFFu : e >> 16;
+                    if (HY && (int32_t)e < 0) {  // rare: second codeword reaches past the index bits
+                        bp += adv;
+                        if (bp >= 32) {
+                            buf = (buf >> 32) | ((uint64_t)nxt << 32);
+                            bp -= 32;
+                            ++wi;
+                            nxt = stage[wi + 2];
+                        }
+                        const uint32_t e1 = tab1[(uint32_t)(buf >> (bp + SH)) & mask1];
+                        w |= (e1 & 15u) << (8 * K * i + 8);
+                        adv = e1 >> 4;
+                    }
                 }
                 bp += adv;
                 if (kReload) pos += adv;
@@ -547,6 +580,14 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
                         const uint32_t w_ = pos >> 5;
                         buf = (uint64_t)stage[w_] | ((uint64_t)stage[w_ + 1] << 32);
                         bp = pos & 31;
+                    } else if (RL == 2) {
+                        const bool t = bp >= 32;
+                        const uint32_t lo = t ? (uint32_t)(buf >> 32) : (uint32_t)buf;
+                        const uint32_t hi = t ? nxt : (uint32_t)(buf >> 32);
+                        buf = (uint64_t)lo | ((uint64_t)hi << 32);
+                        bp &= 31;
+                        wi += t ? 1u : 0u;
+                        nxt = stage[wi + 2];
                     } else if (bp >= 32) {
                         buf = (buf >> 32) | ((uint64_t)nxt << 32);
                         bp -= 32;
@@ -567,8 +608,11 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
 // (in-order vmcnt) never waits for a store.  A chunk whose payload exceeds NR*64 words (more
 // than 3 bits/sample when NR = 24; impossible when NR = 17 and maxlen <= 2) takes the
 // per-symbol routine that reads the stream straight from global memory.
-template <int K, int M, int NR, bool RL>
-__global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
+#ifndef MH_DEC_MIN_WAVES
+#define MH_DEC_MIN_WAVES 1
+#endif
+template <int K, int M, int NR, int RL, bool HY>
+__global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -579,13 +623,29 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
     const uint32_t W = a.W;
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
     uint32_t *tab = smem;
+    // the lookups address the table by raw LDS offset (see decode_staged_chunk)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem != 0u) __builtin_trap();
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (kEntDw << W));
-    {
+    const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
+    if (threadIdx.x < kDtab / 8)
+        reinterpret_cast<uint2 *>(tab1)[threadIdx.x] =
+            reinterpret_cast<const uint2 *>(a.d.dtab + (size_t)ch * kDtab)[threadIdx.x];
+    if (K == 4) {
         const uint32_t *g = reinterpret_cast<const uint32_t *>(a.dtab2) + (((size_t)ch << W) * kEntDw);
         for (uint32_t i = threadIdx.x; i < (kEntDw << W); i += 256) tab[i] = g[i];
-        if (threadIdx.x < kDtab / 8)
-            reinterpret_cast<uint2 *>(tab1)[threadIdx.x] =
-                reinterpret_cast<const uint2 *>(a.d.dtab + (size_t)ch * kDtab)[threadIdx.x];
+    } else {
+        // pair table built in place from the 512-byte per-symbol table (two chained lookups per
+        // entry) instead of streaming 4 << W bytes per workgroup from global memory:
+        // symbol bytes in bits 0-15, bits consumed in 16-30, bit 31 = only one symbol decoded
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < (1u << W); idx += 256) {
+            const uint32_t e1 = tab1[idx & mask1];
+            const uint32_t l1 = e1 >> 4;
+            const uint32_t e2 = tab1[(idx >> l1) & mask1];
+            const uint32_t l2 = e2 >> 4;
+            tab[idx] = l1 + l2 <= W ? (e1 & 15u) | ((e2 & 15u) << 8) | ((l1 + l2) << 16)
+                                    : (e1 & 15u) | (l1 << 16) | 0x80000000u;
+        }
     }
     __syncthreads();
     if ((uint32_t)wave >= nseg) return;
@@ -593,7 +653,6 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
     constexpr uint32_t kCap = NR * 64;
     uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * kCap;
     const uint32_t maskW = (1u << W) - 1u;
-    const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
     const uint32_t *in = a.d.payload + a.d.seg_off[seg];
     uint8_t *out = a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg];
     const uint64_t n = a.d.seg_n[seg];
@@ -628,7 +687,7 @@ __global__ __launch_bounds__(256) void k_decode2(Dec2Args a)
                 if (c + 2 < nfull) hw_next = pay[cur.nw + (lane >> 1)];
             }
             if (staged)
-                decode_staged_chunk<K, M, RL>(hc, tab, maskW, stage, out + (size_t)c * kChunk, lane);
+                decode_staged_chunk<K, M, RL, HY>(hc, tab, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
             else
                 decode_chunk<3, true>(pay_c - kHdrWords, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -102,6 +102,7 @@ struct mh_plan {
     uint32_t n_tasks = 0;
     uint32_t W = 0;  // decode table index bits
     uint32_t dec_K = 4;  // symbols per decode-table lookup
+    uint32_t dec_NR = 32; // staging registers per lane of the hybrid decoder
     uint2 *d_dtab2 = nullptr;  // sized for 8-byte entries; K <= 2 plans use half of it
 };
 
@@ -176,11 +177,11 @@ static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
     return MH_OK;
 }
 
-template <int K, int M, int NR, bool RL>
+template <int K, int M, int NR, int RL, bool HY>
 static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
 {
     const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
-    auto kern = mh::k_decode2<K, M, NR, RL>;
+    auto kern = mh::k_decode2<K, M, NR, RL, HY>;
     if (!st_prepare_only_flag()) {
         hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     } else if (lds > 64 * 1024) {
@@ -220,12 +221,22 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
 static int dispatch_decode(const mh_plan *p, const mh::Dec2Args &a2, hipStream_t st)
 {
     const uint32_t L = p->info.maxlen;
-    static const int force = [] { const char *e = getenv("MH_DEC_RELOAD"); return e ? atoi(e) : -1; }();  // tuning only
-    if (L <= 2) return launch_decode2<4, 4, 17, true>(a2, st);  // worst-case chunk = 1027 words: never oversize
-    const bool rl = force >= 0 ? force != 0 : false;            // measured: reload only pays for K = 4 (profiles/README.md)
-    if (L == 3) return rl ? launch_decode2<2, 2, 25, true>(a2, st) : launch_decode2<2, 2, 25, false>(a2, st);
-    if (L <= 6) return rl ? launch_decode2<2, 2, 32, true>(a2, st) : launch_decode2<2, 2, 32, false>(a2, st);
-    return launch_decode2<1, 2, 32, false>(a2, st);
+    // window maintenance (decode_staged_chunk): 1 = reload, 0 = branchy top-up, 2 = select top-up.
+    // MH_DEC_RELOAD overrides for tuning; defaults are the measured best (profiles/README.md).
+    static const int force = [] { const char *e = getenv("MH_DEC_RELOAD"); return e ? atoi(e) : -1; }();
+    if (L <= 2) return launch_decode2<4, 4, 17, 1, false>(a2, st);  // worst-case chunk = 1027 words: never oversize
+    // measured (profiles/README.md): select top-up for maxlen 3 and the hybrid table, branchy top-up between
+    const int rl = force >= 0 ? force : (L == 3 || a2.W < 2 * L) ? 2 : 0;
+    if (L == 3)
+        return rl == 1 ? launch_decode2<2, 2, 25, 1, false>(a2, st)
+             : rl == 2 ? launch_decode2<2, 2, 25, 2, false>(a2, st) : launch_decode2<2, 2, 25, 0, false>(a2, st);
+    if (a2.W >= 2 * L)
+        return rl == 1 ? launch_decode2<2, 2, 32, 1, false>(a2, st)
+             : rl == 2 ? launch_decode2<2, 2, 32, 2, false>(a2, st) : launch_decode2<2, 2, 32, 0, false>(a2, st);
+    // hybrid pair table: W < 2 * maxlen index bits, one-symbol entries flagged
+    if (p->dec_NR == 31)
+        return rl == 2 ? launch_decode2<2, 2, 31, 2, true>(a2, st) : launch_decode2<2, 2, 31, 0, true>(a2, st);
+    return launch_decode2<2, 2, 32, 0, true>(a2, st);
 }
 
 // raise the dynamic-LDS limits of the kernels this plan will launch (once, at plan creation)
@@ -371,9 +382,21 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
     p->info.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
     p->n_tiles = tile_ch.size();
     p->n_tasks = (uint32_t)task_seg0.size();
-    // decode table: K symbols per lookup, W = K * maxlen index bits (<= 12)
-    p->dec_K = I.maxlen <= 2 ? 4 : I.maxlen <= 6 ? 2 : 1;
+    // decode table: K symbols per lookup, W index bits.  maxlen <= 5: W = K * maxlen (<= 10), every
+    // entry holds K whole codewords; longer codes: hybrid pair table of 10 index bits and 31
+    // staging registers, which keeps 4 workgroups per CU (tables + staging <= 40 KiB of LDS).
+    // MH_DEC_W / MH_DEC_NR: tuning overrides (index-bit cap 8..12, staging registers 31|32).
+    p->dec_K = I.maxlen <= 2 ? 4 : 2;
     p->W = p->dec_K * I.maxlen;
+    p->dec_NR = 32;
+    if (p->dec_K == 2) {
+        static const int w_env = [] { const char *e = getenv("MH_DEC_W"); return e ? atoi(e) : 0; }();
+        static const int nr_env = [] { const char *e = getenv("MH_DEC_NR"); return e ? atoi(e) : 0; }();
+        uint32_t cap = w_env >= 8 && w_env <= 12 ? (uint32_t)w_env : 10u;
+        if (cap < I.maxlen) cap = I.maxlen;  // a flagged entry still holds its first codeword
+        if (p->W > cap) p->W = cap;
+        if (p->W < 2 * I.maxlen) p->dec_NR = nr_env == 32 ? 32 : 31;
+    }
     // codebooks by rank: bit-reversed code (first code bit at bit 0) | len << 16
     std::vector<uint32_t> codes((size_t)K * 16, 0);
     for (uint32_t k = 0; k < K; ++k) {
@@ -396,7 +419,7 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
         (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_dtab, (size_t)C * mh::kDtab)) ||
         (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
         (rc = upload(&p->d_task_seg0, task_seg0)) || (rc = upload(&p->d_task_n, task_n)) ||
-        (rc = alloc(&p->d_dtab2, (size_t)C << p->W)))
+        (p->dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << p->W))))
         return rc;
     return MH_OK;
 }

@@ -182,6 +182,11 @@ def test_unaligned_buffer_and_many_encoders(mh):
     (4, 0, "top", [[1, 2, 3, 3]]),                      # every sample 3 bits: exactly the maxlen-3 worst case
     (10, 0, "top", [[1, 2, 3, 4, 5, 6, 7, 8, 9, 9]]),   # every sample 9 bits: far beyond any LDS cap
     (6, 0, "uniform", [[1, 2, 3, 4, 5, 5]]),
+    # mostly zeros with runs of the top symbol: ~1.3 bits/sample (fast paths), but four 9-bit
+    # codewords exceed a dword (encoder escape) and two exceed the pair table's index (decoder flag)
+    (10, 0, "bursts", [[1, 2, 3, 4, 5, 6, 7, 8, 9, 9]]),
+    (8, 0, "bursts", [[1, 2, 3, 4, 5, 6, 7, 7]]),
+    (10, 1, "bursts", None),
 ])
 def test_slow_paths_for_incompressible_data(mh, S, mode, gen, rows):
     """Data that needs > 3 bits/sample overflows the capped LDS staging (encoder) and the staged
@@ -190,6 +195,14 @@ def test_slow_paths_for_incompressible_data(mh, S, mode, gen, rows):
     lens = [16384 * 3, 16384 + 5000, 70001, 16384, 100, 40000]
     if gen == "uniform":
         chans = [rng.randint(0, 13, size=T).astype(np.uint8) for T in lens]
+    elif gen == "bursts":
+        chans = []
+        for T in lens:
+            x = (rng.random_sample(T) < 0.02).astype(np.uint8)
+            for start in rng.randint(0, T, size=max(T // 150, 1)):
+                x[start:start + rng.randint(1, 12)] = rng.randint(S - 4, S + 2)
+            x[:16] = 0  # calibration window (h=4): all zeros, so the peak is symbol 0
+            chans.append(x)
     else:
         chans = [np.full(T, S - 1, np.uint8) for T in lens]
         chans[2][::7] = 0
