@@ -5,7 +5,7 @@
 //   k_hist<NS>       window histogram for S <= 3, byte-parallel compares, 16 B/lane reads
 //   k_finalize       rank-map the histogram, bits = SCLV[enc] . post
 //   decode_chunk     per-symbol decoder straight from global memory (partial / oversize chunks)
-//   k_scan_words / k_compact   dense re-packing of the segment slots
+//   k_scan_* / k_compact       dense re-packing of the segment slots
 //   k_synth          synthetic MUA generator
 // The encoder / decoder proper are in mh_codec2.hpp, layout kernels in mh_layout.hpp.
 //
@@ -341,15 +341,38 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in
 // ------------------------------------------------------------------------------------------
 // dense re-packing
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_words(const uint64_t *seg_words, uint64_t nseg,
-                                                     uint64_t *dense_off, uint64_t *total)
+// Exclusive scan of the per-segment word counts in three small launches: block sums (coalesced,
+// 2048 segments per workgroup), a one-workgroup scan of the block sums, and the in-block scan
+// that writes the offsets.  (A single workgroup striding over every segment took longer than
+// the copy itself at 3e5 segments.)
+constexpr uint32_t kScanBlock = 2048;  // segments per workgroup = 256 threads x 8
+
+__global__ __launch_bounds__(256) void k_scan_block_sums(const uint64_t *seg_words, uint64_t nseg, uint64_t *block_sum)
+{
+    __shared__ uint64_t red[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanBlock;
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint64_t i = base + (uint64_t)j * 256 + threadIdx.x;
+        if (i < nseg) s += seg_words[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// in place: block_sum[b] -> sum of the blocks before b; total[0] = everything
+__global__ __launch_bounds__(1024) void k_scan_top(uint64_t *block_sum, uint64_t nblocks, uint64_t *total)
 {
     __shared__ uint64_t part[1024];
     const int tid = threadIdx.x;
-    const uint64_t per = (nseg + 1023) / 1024;
-    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < nseg ? lo + per : nseg;
+    const uint64_t per = (nblocks + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < nblocks ? lo + per : nblocks;
     uint64_t s = 0;
-    for (uint64_t i = lo; i < hi; ++i) s += seg_words[i];
+    for (uint64_t i = lo; i < hi; ++i) s += block_sum[i];
     part[tid] = s;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -360,26 +383,76 @@ __global__ __launch_bounds__(1024) void k_scan_words(const uint64_t *seg_words, 
     }
     uint64_t run = part[tid] - s;
     for (uint64_t i = lo; i < hi; ++i) {
-        dense_off[i] = run;
-        run += seg_words[i];
+        const uint64_t v = block_sum[i];
+        block_sum[i] = run;
+        run += v;
     }
     if (tid == 1023) total[0] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void k_compact(const uint32_t *payload, const uint64_t *seg_off,
-                                                 const uint64_t *seg_words,
-                                                 const uint64_t *dense_off, uint32_t *dense,
-                                                 uint64_t dense_cap)
+__global__ __launch_bounds__(256) void k_scan_apply(const uint64_t *seg_words, uint64_t nseg, const uint64_t *block_base,
+                                                    uint64_t *dense_off)
 {
-    const uint32_t seg = blockIdx.x;
-    const uint64_t n = seg_words[seg], d0 = dense_off[seg];
-    if (d0 + n > dense_cap) return;  // host checks total_words afterwards
-    const uint32_t *src = payload + seg_off[seg];  // slots start on 128-byte lines
-    uint32_t *dst = dense + d0;                    // word-aligned only: unaligned 16-byte stores
-    const uint64_t nv = n >> 2;
-    for (uint64_t i = threadIdx.x; i < nv; i += 256)
-        *reinterpret_cast<u32x4_u *>(dst + 4 * i) = *reinterpret_cast<const u32x4_u *>(src + 4 * i);
-    if (threadIdx.x < (n & 3)) dst[4 * nv + threadIdx.x] = src[4 * nv + threadIdx.x];
+    __shared__ uint64_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * kScanBlock;
+    uint64_t run = block_base[blockIdx.x];
+    for (int j = 0; j < 8; ++j) {  // rows of 256 consecutive segments
+        const uint64_t i = base + (uint64_t)j * 256 + threadIdx.x;
+        const uint64_t v = i < nseg ? seg_words[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        __syncthreads();  // wsum of the previous row consumed
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < nseg) dense_off[i] = run + before + incl - v;
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
+// One wave per segment, kCompactSegs segments per workgroup (a segment is only a few KiB: one
+// workgroup per segment is dispatch-bound).  The destination is word-aligned only, so up to 3
+// head words are peeled off to make the 16-byte stores aligned; the loads take the misalignment.
+constexpr uint32_t kCompactSegs = 16;
+
+__global__ __launch_bounds__(256) void k_compact(const uint32_t *__restrict__ payload, const uint64_t *seg_off,
+                                                 const uint64_t *seg_words, const uint64_t *dense_off,
+                                                 uint32_t *__restrict__ dense, uint64_t dense_cap, uint64_t nseg)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t s = wave; s < kCompactSegs; s += 4) {
+        const uint64_t seg = (uint64_t)blockIdx.x * kCompactSegs + s;
+        if (seg >= nseg) return;
+        const uint64_t n = seg_words[seg], d0 = dense_off[seg];
+        if (d0 + n > dense_cap) continue;  // host checks total_words afterwards
+        const uint32_t *src = payload + seg_off[seg];  // slots start on 128-byte lines
+        uint32_t *dst = dense + d0;
+        uint64_t head = (4 - (d0 & 3)) & 3;
+        if (head > n) head = n;
+        if (lane < head) dst[lane] = src[lane];
+        const uint64_t nv = (n - head) >> 2;
+        for (uint64_t i0 = 0; i0 < nv; i0 += 8 * 64) {  // 8 KiB per wave in flight (a typical segment is < 6 KiB)
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint64_t i = i0 + (uint64_t)j * 64 + lane;
+                if (i < nv) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(src + head + 4 * i));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint64_t i = i0 + (uint64_t)j * 64 + lane;
+                if (i < nv) __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4 *>(dst + head + 4 * i));
+            }
+        }
+        const uint64_t done = head + 4 * nv;
+        if (lane < n - done) dst[done + lane] = src[done + lane];
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,9 +1,11 @@
 // mh_layout.hpp -- data-layout kernels either side of the codec.
 //
+//   k_rebin3<SAT>    fast path of the same for r >= 4 (see below)
 //   k_rebin2<SAT>    per-channel re-binning (ref: Compressing data/functions_1.py:11-24 and the
 //                    MATLAB histogram2 binning, Data/Load_and_bin_Sabes_store_as_mat_file.m:50-54):
 //                    a workgroup stages a contiguous 32 KiB span of one channel in LDS with
 //                    16-byte loads, then each thread sums its r bytes with v_sad_u8 on dwords.
+//   k_deinterleave2  the same transposition as k_deinterleave with dword-only LDS traffic (below)
 //   k_deinterleave   time-major interleaved samples |CH1|CH2|...|CHN| per time step (the FPGA's
 //                    compression-phase input order, ref: FPGA implementation/README.md:31) ->
 //                    the channel-major layout the codec reads.  256(t) x 64(c) byte tiles
@@ -64,6 +66,123 @@ __global__ __launch_bounds__(256) void k_rebin2(const uint8_t *__restrict__ data
     }
 }
 
+// k_rebin3: the fast path for r >= 4.  A "unit" is g = 4 / gcd(r, 4) bins = u = g * r / 4 whole
+// dwords, so every unit has the same dword/bin structure and the walk over it is wave-uniform:
+// one v_sad_u8 per dword, one masked split where a bin boundary cuts a dword (scalar masks).
+// Thread i of a pass owns unit i (u is odd for r = 5, 10, 20, 50, 100: conflict-free LDS reads)
+// and stores its g results as one 4/2/1-byte (uint8 output) or 16/8/4-byte (uint32) access.
+// A workgroup walks `tpw` consecutive tiles of one channel; the next tile's 16-byte loads are
+// issued into registers before the current tile is summed.
+template <bool SAT>
+__global__ __launch_bounds__(256) void k_rebin3(const uint8_t *__restrict__ data, const uint64_t *in_off,
+                                                const uint64_t *in_len, uint32_t C, uint32_t r, uint32_t g,
+                                                uint32_t u, uint32_t upt, uint32_t tpw, void *__restrict__ out,
+                                                const uint64_t *out_off)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kRebinTileBytes / 4];
+    const uint32_t tile_bytes = upt * u * 4;  // <= kRebinTileBytes
+    constexpr int kVec = kRebinTileBytes / 16 / 256;  // 16-byte vectors per thread and tile
+    for (uint32_t ch = blockIdx.y; ch < C; ch += gridDim.y) {
+        const uint64_t T = in_len[ch], nb = (T + r - 1) / r;
+        const uint8_t *x = data + in_off[ch];
+        const uint64_t ntiles = (T + tile_bytes - 1) / tile_bytes;
+        for (uint64_t tile0 = (uint64_t)blockIdx.x * tpw; tile0 < ntiles; tile0 += (uint64_t)gridDim.x * tpw) {
+            const uint64_t tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
+            u32x4 R[kVec];
+            auto fetch = [&](uint64_t t) {
+                const uint64_t b0 = t * tile_bytes;
+                const uint32_t nbytes = T - b0 < tile_bytes ? (uint32_t)(T - b0) : tile_bytes;
+#pragma unroll
+                for (int j = 0; j < kVec; ++j) {
+                    const uint32_t o = ((uint32_t)j * 256 + threadIdx.x) * 16;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (o + 16 <= nbytes) {
+                        v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(x + b0 + o));
+                    } else if (o < nbytes) {  // ragged end of the channel: byte by byte, zero padded
+                        for (uint32_t k = 0; o + k < nbytes; ++k) v[k >> 2] |= (uint32_t)x[b0 + o + k] << (8 * (k & 3));
+                    }
+                    R[j] = v;
+                }
+            };
+            fetch(tile0);
+            for (uint64_t t = tile0; t < tend; ++t) {
+                __syncthreads();  // previous tile fully summed
+#pragma unroll
+                for (int j = 0; j < kVec; ++j) {
+                    const uint32_t i = (uint32_t)j * 256 + threadIdx.x;
+                    if (i * 16 < tile_bytes) reinterpret_cast<u32x4 *>(tile)[i] = R[j];
+                }
+                __syncthreads();
+                if (t + 1 < tend) fetch(t + 1);
+                const uint64_t bin0 = t * upt * g;  // first bin of this tile
+                for (uint32_t idx = threadIdx.x; idx < upt; idx += 256) {
+                    const uint64_t b = bin0 + (uint64_t)idx * g;
+                    if (b >= nb) break;
+                    const uint32_t *p = tile + idx * u;
+                    uint32_t acc = 0, rem = r, k = 0, packed = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+                    auto emit = [&](uint32_t v) {
+                        if (SAT) {
+                            packed |= (v > 255u ? 255u : v) << (8 * k);
+                        } else {
+                            o0 = k == 0 ? v : o0;
+                            o1 = k == 1 ? v : o1;
+                            o2 = k == 2 ? v : o2;
+                            o3 = k == 3 ? v : o3;
+                        }
+                        ++k;
+                    };
+                    auto step = [&](uint32_t v) {
+                        if (rem >= 4) {
+                            acc = __builtin_amdgcn_sad_u8(v, 0u, acc);
+                            rem -= 4;
+                        } else {  // bin boundary inside this dword (rem = 1..3 low bytes finish the bin)
+                            const uint32_t m = (1u << (8 * rem)) - 1u;
+                            emit(__builtin_amdgcn_sad_u8(v & m, 0u, acc));
+                            acc = __builtin_amdgcn_sad_u8(v & ~m, 0u, 0u);
+                            rem = r - (4 - rem);
+                        }
+                        if (rem == 0) {
+                            emit(acc);
+                            acc = 0;
+                            rem = r;
+                        }
+                    };
+                    // LDS reads batched 8 ahead of the (wave-uniform) walk so their latency overlaps
+                    for (uint32_t w0 = 0; w0 < u; w0 += 8) {
+                        uint32_t vv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) vv[j] = w0 + j < u ? p[w0 + j] : 0u;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (w0 + j < u) step(vv[j]);
+                    }
+                    const uint32_t valid = nb - b < g ? (uint32_t)(nb - b) : g;
+                    if (SAT) {
+                        uint8_t *q = reinterpret_cast<uint8_t *>(out) + out_off[ch] + b;
+                        if (valid == 4) {
+                            *reinterpret_cast<uint32_t __attribute__((aligned(1))) *>(q) = packed;
+                        } else if (valid == 2 && g == 2) {
+                            *reinterpret_cast<uint16_t __attribute__((aligned(1))) *>(q) = (uint16_t)packed;
+                        } else {
+                            for (uint32_t j = 0; j < valid; ++j) q[j] = (uint8_t)(packed >> (8 * j));
+                        }
+                    } else {
+                        uint32_t *q = reinterpret_cast<uint32_t *>(out) + out_off[ch] + b;
+                        if (valid == 4) {
+                            const u32x4 v4 = {o0, o1, o2, o3};
+                            *reinterpret_cast<u32x4_u *>(q) = v4;
+                        } else {
+                            if (valid > 0) q[0] = o0;
+                            if (valid > 1) q[1] = o1;
+                            if (valid > 2) q[2] = o2;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 constexpr int kTrT = 256, kTrC = 64, kTrPitch = kTrC + 4;  // LDS row pitch (bytes)
 
 // in: [T][C] bytes (time-major).  out channel c: bytes out + out_off[c] + t.
@@ -109,6 +228,121 @@ __global__ __launch_bounds__(256) void k_deinterleave(const uint8_t *__restrict_
                     *reinterpret_cast<u32x4_u *>(dst + v * 16) = o;
                 } else {
                     for (uint32_t k = tb; k < th; ++k) dst[k - tq] = tile[k * kTrPitch + c];
+                }
+            }
+        }
+    }
+}
+
+// k_deinterleave2: 256(t) x 128(c) byte tiles, dword-granular LDS traffic only.
+//   load : 8 x 16-byte global reads per thread (128 contiguous bytes per time step), written to
+//          LDS as dwords (dword column = 4 channels) at column ^ swz(row);
+//   turn : a thread owns 4 channels x 16 time steps: 16 ds_read_b32 (one per row), four 4x4 byte
+//          transposes with v_perm_b32, 4 x 16-byte stores; 16 consecutive lanes cover 256
+//          contiguous bytes of one channel.
+//   swz(row) = 2 * (row / 16 % 16) ^ (row % 4) makes both LDS phases conflict-free: the reads
+//   of a half-wave (2 column groups x 16 time blocks, same row % 16) and the writes of a
+//   half-wave (4 consecutive rows x 8 quarters) each hit 32 distinct banks.
+//   A workgroup walks `tpw` consecutive tiles of its 128-channel strip; other workgroups of the
+//   CU cover its load latency (holding the next tile in registers across the turn costs 180
+//   VGPRs and the occupancy that hides more).
+constexpr int kTr2T = 256, kTr2C = 128;
+
+// ragged-edge helpers of k_deinterleave2, kept out of line so the hot path's register
+// allocation is not shaped by them
+__device__ __noinline__ u32x4 tr2_load_partial(const uint8_t *src, uint32_t n)
+{
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t k = 0; k < n; ++k) w[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
+    const u32x4 v = {w[0], w[1], w[2], w[3]};
+    return v;
+}
+
+__device__ __noinline__ void tr2_store_partial(uint8_t *dst, u32x4 o, uint32_t n)
+{
+    const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+    for (uint32_t t = 0; t < n; ++t) dst[t] = (uint8_t)(w[t >> 2] >> (8 * (t & 3)));
+}
+
+__device__ __forceinline__ uint32_t tr2_swz(uint32_t row) { return (((row >> 4) & 15u) << 1) ^ (row & 3u); }
+
+__global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict__ in, uint64_t T, uint32_t C,
+                                                       uint32_t tpw, uint8_t *__restrict__ out,
+                                                       const uint64_t *out_off)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kTr2T * (kTr2C / 4)];
+    const uint32_t c0 = blockIdx.y * kTr2C;
+    const uint32_t cw = C - c0 < (uint32_t)kTr2C ? C - c0 : (uint32_t)kTr2C;
+    const uint64_t ntiles = (T + kTr2T - 1) / kTr2T;
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * tpw; tile0 < ntiles; tile0 += (uint64_t)gridDim.x * tpw) {
+        const uint64_t tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
+        u32x4 V[8];
+        auto fetch = [&](uint64_t tl) {
+            const uint64_t t0 = tl * kTr2T;
+            const uint32_t th = T - t0 < (uint64_t)kTr2T ? (uint32_t)(T - t0) : (uint32_t)kTr2T;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t i = (uint32_t)j * 256 + threadIdx.x, row = i >> 3, q = (i & 7) * 16;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (row < th) {
+                    const uint8_t *src = in + (t0 + row) * C + c0 + q;
+                    if (q + 16 <= cw) {
+                        v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(src));
+                    } else if (q < cw) {
+                        v = tr2_load_partial(src, cw - q);
+                    }
+                }
+                V[j] = v;
+            }
+        };
+        for (uint64_t tl = tile0; tl < tend; ++tl) {
+            const uint64_t t0 = tl * kTr2T;
+            const uint32_t th = T - t0 < (uint64_t)kTr2T ? (uint32_t)(T - t0) : (uint32_t)kTr2T;
+            fetch(tl);
+            __syncthreads();  // previous tile fully turned
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t i = (uint32_t)j * 256 + threadIdx.x, row = i >> 3, q4 = (i & 7) * 4;
+                const uint32_t sw = tr2_swz(row);
+                uint32_t *r = tile + row * (kTr2C / 4);
+                r[(q4 + 0) ^ sw] = V[j].x;
+                r[(q4 + 1) ^ sw] = V[j].y;
+                r[(q4 + 2) ^ sw] = V[j].z;
+                r[(q4 + 3) ^ sw] = V[j].w;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int uu = 0; uu < 2; ++uu) {
+                const uint32_t id = threadIdx.x + 256u * uu, tb = id & 15u, cg = id >> 4;
+                if (cg * 4 >= cw || tb * 16 >= th) continue;
+                uint32_t d[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    d[i] = tile[(tb * 16 + i) * (kTr2C / 4) + (cg ^ (tb << 1) ^ (uint32_t)(i & 3))];
+                u32x4 o[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {  // rows 4m..4m+3 -> dword m of each channel's 16 bytes
+                    const uint32_t a = d[4 * m], b = d[4 * m + 1], c = d[4 * m + 2], e = d[4 * m + 3];
+                    const uint32_t t0_ = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+                    const uint32_t t1_ = __builtin_amdgcn_perm(e, c, 0x05010400u);  // c0 e0 c1 e1
+                    const uint32_t t2_ = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+                    const uint32_t t3_ = __builtin_amdgcn_perm(e, c, 0x07030602u);
+                    o[0][m] = __builtin_amdgcn_perm(t1_, t0_, 0x05040100u);
+                    o[1][m] = __builtin_amdgcn_perm(t1_, t0_, 0x07060302u);
+                    o[2][m] = __builtin_amdgcn_perm(t3_, t2_, 0x05040100u);
+                    o[3][m] = __builtin_amdgcn_perm(t3_, t2_, 0x07060302u);
+                }
+                const bool whole = tb * 16 + 16 <= th;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = cg * 4 + k;
+                    if (c >= cw) break;
+                    uint8_t *dst = out + out_off[c0 + c] + t0 + tb * 16;
+                    if (whole) {
+                        __builtin_nontemporal_store(o[k], reinterpret_cast<u32x4_u *>(dst));
+                    } else {
+                        tr2_store_partial(dst, o[k], th - tb * 16);
+                    }
                 }
             }
         }

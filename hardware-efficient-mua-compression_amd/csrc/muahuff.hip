@@ -103,6 +103,7 @@ struct mh_plan {
     uint32_t W = 0;  // decode table index bits
     uint32_t dec_K = 4;  // symbols per decode-table lookup
     uint32_t dec_NR = 32; // staging registers per lane of the hybrid decoder
+    uint64_t *d_scan = nullptr;  // block sums of mh_compact's segment scan
     uint2 *d_dtab2 = nullptr;  // sized for 8-byte entries; K <= 2 plans use half of it
 };
 
@@ -307,7 +308,7 @@ int mh_plan_destroy(mh_plan *p)
     void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
-                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_dtab2};
+                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_dtab2, p->d_scan};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -419,7 +420,8 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
         (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_dtab, (size_t)C * mh::kDtab)) ||
         (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
         (rc = upload(&p->d_task_seg0, task_seg0)) || (rc = upload(&p->d_task_n, task_n)) ||
-        (p->dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << p->W))))
+        (p->dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << p->W))) ||
+        (rc = alloc(&p->d_scan, p->seg_ch.size() / mh::kScanBlock + 2)))
         return rc;
     return MH_OK;
 }
@@ -650,12 +652,19 @@ int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, u
         return fail(MH_ERR_ARG, "mh_compact: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     const uint64_t nseg = p->info.n_segments;
-    hipLaunchKernelGGL(mh::k_scan_words, dim3(1), dim3(1024), 0, st, seg_words, nseg, dense_off, total_words);
+    const uint64_t nblocks = (nseg + mh::kScanBlock - 1) / mh::kScanBlock;
+    if (nblocks)
+        hipLaunchKernelGGL(mh::k_scan_block_sums, dim3((unsigned)nblocks), dim3(256), 0, st, seg_words, nseg, p->d_scan);
+    hipLaunchKernelGGL(mh::k_scan_top, dim3(1), dim3(1024), 0, st, p->d_scan, nblocks, total_words);
+    if (nblocks)
+        hipLaunchKernelGGL(mh::k_scan_apply, dim3((unsigned)nblocks), dim3(256), 0, st, seg_words, nseg,
+                           (const uint64_t *)p->d_scan, dense_off);
     MH_HIP(hipGetLastError());
     if (nseg) {
-        hipLaunchKernelGGL(mh::k_compact, dim3((unsigned)nseg), dim3(256), 0, st, payload,
+        const uint64_t nwg = (nseg + mh::kCompactSegs - 1) / mh::kCompactSegs;
+        hipLaunchKernelGGL(mh::k_compact, dim3((unsigned)nwg), dim3(256), 0, st, payload,
                            (const uint64_t *)p->d_seg_off, seg_words, (const uint64_t *)dense_off,
-                           dense, dense_cap_words);
+                           dense, dense_cap_words, nseg);
         MH_HIP(hipGetLastError());
     }
     return MH_OK;
@@ -682,11 +691,32 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
     if (!data || !in_off || !in_len || !out || !out_off || C == 0 || r == 0)
         return fail(MH_ERR_ARG, "mh_rebin: bad argument");
     if (r > 4096) return fail(MH_ERR_ARG, "mh_rebin: r=%u above 4096", r);
+    const uint32_t by = C > 65535 ? 65535 : C;
+    if (r >= 4) {
+        // unit = g bins = u whole dwords; tile = upt units (<= 32 KiB, whole passes of 256 threads
+        // when there are that many); a workgroup walks 4 consecutive tiles of a channel
+        const uint32_t g = r % 4 == 0 ? 1u : r % 2 == 0 ? 2u : 4u;
+        const uint32_t u = g * r / 4;
+        uint32_t upt = mh::kRebinTileBytes / 4 / u;
+        if (upt >= 256) upt -= upt % 256;
+        const uint32_t tpw = 4;
+        const uint64_t tile_bytes = (uint64_t)upt * u * 4;
+        uint64_t bx = ((max_len + tile_bytes - 1) / tile_bytes + tpw - 1) / tpw;
+        if (bx == 0) bx = 1;
+        if (bx > 65535) bx = 65535;
+        if (saturate)
+            hipLaunchKernelGGL(mh::k_rebin3<true>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
+                               data, in_off, in_len, C, r, g, u, upt, tpw, out, out_off);
+        else
+            hipLaunchKernelGGL(mh::k_rebin3<false>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
+                               data, in_off, in_len, C, r, g, u, upt, tpw, out, out_off);
+        MH_HIP(hipGetLastError());
+        return MH_OK;
+    }
     const uint64_t bins_per_tile = mh::kRebinTileBytes / r;
     uint64_t bx = ((max_len + r - 1) / r + bins_per_tile - 1) / bins_per_tile;
     if (bx == 0) bx = 1;
     if (bx > 4096) bx = 4096;
-    const uint32_t by = C > 65535 ? 65535 : C;
     if (saturate)
         hipLaunchKernelGGL(mh::k_rebin2<true>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
                            data, in_off, in_len, C, r, out, out_off);
@@ -702,12 +732,13 @@ int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, con
 {
     if (!in || !out || !out_off || C == 0) return fail(MH_ERR_ARG, "mh_deinterleave: bad argument");
     if (T == 0) return MH_OK;
-    uint64_t bx = (T + mh::kTrT - 1) / mh::kTrT;
-    if (bx > 2048) bx = 2048;
-    const uint32_t by = (C + mh::kTrC - 1) / mh::kTrC;
+    const uint32_t tpw = 4;
+    uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
+    if (bx > 0x7FFFFFFFull) bx = 0x7FFFFFFFull;
+    const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
     if (by > 65535) return fail(MH_ERR_ARG, "mh_deinterleave: C=%u too large", C);
-    hipLaunchKernelGGL(mh::k_deinterleave, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, out,
-                       out_off);
+    hipLaunchKernelGGL(mh::k_deinterleave2, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                       out, out_off);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }

@@ -297,19 +297,19 @@ def test_rebin_kernel_all_periods(mh):
     ragged channels, both output flavours (uint8 saturating like MATLAB, uint32 exact)."""
     import ctypes as ct
     rng = np.random.RandomState(12)
-    lens = [1, 4, 99, 100, 101, 32768, 32769, 100003, 250000]
+    lens = [1, 4, 99, 100, 101, 32768, 32769, 100003, 250000, 700001]
     chans = [rng.randint(0, 9, size=T).astype(np.uint8) for T in lens]
     chans[3][:] = 255
     cs = _cs(mh, chans)
     lib = mh._lib.lib()
     d_off = torch.from_numpy(cs.ch_off.astype(np.int64)).cuda()
     d_len = torch.from_numpy(cs.ch_len.astype(np.int64)).cuda()
-    for r in (1, 2, 5, 10, 20, 50, 100):
+    for r in (1, 2, 3, 4, 5, 6, 7, 10, 13, 20, 50, 64, 100, 1000, 4095, 4096):
         nb = [-(-T // r) for T in lens]
         ooff = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int64)
         d_ooff = torch.from_numpy(ooff).cuda()
         for sat in (0, 1):
-            out = torch.zeros(sum(nb), dtype=torch.uint8 if sat else torch.int32, device="cuda")
+            out = torch.full((sum(nb) + 64,), 0x5A, dtype=torch.uint8 if sat else torch.int32, device="cuda")
             mh._lib.check(lib.mh_rebin(ct.c_void_p(cs.data.data_ptr()), ct.c_void_p(d_off.data_ptr()),
                                        ct.c_void_p(d_len.data_ptr()), len(lens), max(lens), r, sat,
                                        ct.c_void_p(out.data_ptr()), ct.c_void_p(d_ooff.data_ptr()), None))
@@ -317,9 +317,11 @@ def test_rebin_kernel_all_periods(mh):
             for c, x in enumerate(chans):
                 want = OC.rebin_u8(x, r) if sat else OC.rebin_u32(x, r)
                 assert np.array_equal(got[ooff[c]:ooff[c] + nb[c]].astype(np.int64), want.astype(np.int64)), (r, sat, c)
+            assert (got[sum(nb):] == 0x5A).all(), (r, sat)  # nothing written past the last bin
 
 
-@pytest.mark.parametrize("T,C", [(1, 1), (255, 3), (256, 64), (1000, 96), (4097, 130), (70000, 17)])
+@pytest.mark.parametrize("T,C", [(1, 1), (255, 3), (256, 64), (1000, 96), (4097, 130), (70000, 17), (513, 128),
+                                 (777, 257), (2048, 1024), (15, 4), (16, 5), (3000, 143)])
 def test_deinterleave_time_major_stream(mh, T, C):
     """|CH1|CH2|...|CHN| per time step -> channel-major, then the codec runs on it unchanged."""
     rng = np.random.RandomState(T + C)
