@@ -22,6 +22,7 @@ class StreamEncoder:
         self.seg_chunks = int(seg_chunks)
         self.device = torch.device(device, torch.cuda.current_device()) if device == "cuda" else torch.device(device)
         self.peak = self.enc = None
+        self._slots = {}
 
     def calibrate(self, block):
         """block: [T0, C] time-major counts holding at least 2^hist_bits time steps (fewer are
@@ -35,25 +36,63 @@ class StreamEncoder:
         plan.close()
         return self.peak, self.enc
 
+    def _slot(self, Tb):
+        """Plan and device buffers for blocks of Tb time steps, built once and reused: in the
+        compression phase every block has the same shape, so nothing is planned or allocated
+        per block."""
+        slot = self._slots.get(Tb)
+        if slot is None:
+            cs = ChannelSet.empty([Tb] * self.C, device=self.device)
+            plan = codec.Plan(cs.ch_off, cs.ch_len, self.S, 0, self.mode, WIN_FULL, self.sclv,
+                              seg_chunks=self.seg_chunks)
+            slot = dict(cs=cs, plan=plan, enc=plan.alloc_encoded(),
+                        d_off=torch.from_numpy(cs.ch_off.astype(np.int64)).to(self.device),
+                        dense=torch.empty(plan.payload_cap_words, dtype=torch.int32, device=self.device))
+            self._slots[Tb] = slot
+        return slot
+
+    def encode_block_device(self, block):
+        """block: [Tb, C] time-major counts (device tensor or host array).  Enqueues
+        de-interleave + preset encode + compaction on the current stream and returns
+        (dense Encoded, total_words tensor, slot) without synchronising; the buffers belong to
+        the shape's slot and are overwritten by the next block of the same shape."""
+        import ctypes as ct
+
+        from . import _lib
+        if self.peak is None:
+            raise RuntimeError("calibrate() first")
+        t = block if isinstance(block, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(block, np.uint8))
+        t = t.to(self.device).contiguous()
+        Tb, C = int(t.shape[0]), int(t.shape[1])
+        if C != self.C:
+            raise ValueError("block has %d channels, encoder was built for %d" % (C, self.C))
+        slot = self._slot(Tb)
+        cs, plan = slot["cs"], slot["plan"]
+        _lib.check(_lib.lib().mh_deinterleave(ct.c_void_p(t.data_ptr()), Tb, C, ct.c_void_p(cs.data.data_ptr()),
+                                              ct.c_void_p(slot["d_off"].data_ptr()),
+                                              ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        enc = plan.encode(cs.data, out=slot["enc"], preset=(self.peak, self.enc))
+        dense, tot = plan.compact(enc, dense=slot["dense"])
+        return dense, tot, slot
+
     def encode_block(self, block):
         """block: [Tb, C] time-major counts -> container_io.Compressed covering all Tb bins of
         every channel, coded with the stored RAM word."""
-        if self.peak is None:
-            raise RuntimeError("calibrate() first")
-        cs = ChannelSet.from_time_major(block, device=self.device)
-        plan = codec.Plan(cs.ch_off, cs.ch_len, self.S, 0, self.mode, WIN_FULL, self.sclv, seg_chunks=self.seg_chunks)
-        enc = plan.encode(cs.data, preset=(self.peak, self.enc))
-        dense, tot = plan.compact(enc)
+        dense, tot, slot = self.encode_block_device(block)
+        plan, cs, enc = slot["plan"], slot["cs"], slot["enc"]
         torch.cuda.synchronize()
         total = int(tot.item())
         hdr = container_io.make_header(self.S, 0, self.mode, WIN_FULL, self.seg_chunks, self.sclv)
         hdr["preset"] = True
-        c = container_io.Compressed(hdr, cs.ch_len.copy(), enc.peak.cpu().numpy(), enc.enc.cpu().numpy(),
-                                    enc.skipped.cpu().numpy(), enc.ch_bits.cpu().numpy().astype(np.uint64),
-                                    enc.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments],
-                                    dense.payload[:total].cpu().numpy().view(np.uint32).copy())
-        plan.close()
-        return c
+        return container_io.Compressed(hdr, cs.ch_len.copy(), enc.peak.cpu().numpy(), enc.enc.cpu().numpy(),
+                                       enc.skipped.cpu().numpy(), enc.ch_bits.cpu().numpy().astype(np.uint64),
+                                       enc.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments],
+                                       dense.payload[:total].cpu().numpy().view(np.uint32).copy())
+
+    def close(self):
+        for slot in self._slots.values():
+            slot["plan"].close()
+        self._slots = {}
 
     @staticmethod
     def decode_block(c, device="cuda"):

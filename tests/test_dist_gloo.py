@@ -98,3 +98,61 @@ def test_shard_channels_partition():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_pipelined(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from muahuff import dist as mdist
+    OC = oracle.c
+    chans = _channels()
+    lo, hi = mdist.shard_channels(len(chans), world, rank)
+    tab = np.array([[1, 2, 3, 4, 4], [2, 2, 2, 3, 3], [1, 3, 3, 3, 3]], np.uint8)
+    p = OC.Params(5, 6, 1, OC.WIN_AFTER_CAL, tab, seg_chunks=2)
+    produced = []
+
+    def blocks(nblocks=3):  # this rank's channels in 3 channel blocks (some may be empty)
+        n = hi - lo
+        for b in range(nblocks):
+            b0, b1 = mdist.shard_channels(n, nblocks, b)
+            produced.append(b)
+            if b1 == b0:
+                yield torch.zeros(0, dtype=torch.int32), 0
+                continue
+            data, off, ln = OC.flatten(chans[lo + b0:lo + b1])
+            dense = _dense(OC, OC.encode(data, off, ln, p))
+            yield torch.from_numpy(dense.view(np.int32).copy()), torch.tensor([len(dense)])
+
+    pay, offs = mdist.gather_payload_pipelined(blocks())
+    assert produced == [0, 1, 2]
+    if rank == 0:
+        q.put(dict(payload=pay[:int(offs[-1, 0])].numpy().view(np.uint32).copy(), offs=offs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_gather_equals_single_process_stream(world):
+    """Channel blocks sent while later blocks are still being produced arrive in channel order."""
+    import oracle
+    OC = oracle.c
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    got = q.get(timeout=120)
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    chans = _channels()
+    tab = np.array([[1, 2, 3, 4, 4], [2, 2, 2, 3, 3], [1, 3, 3, 3, 3]], np.uint8)
+    p = OC.Params(5, 6, 1, OC.WIN_AFTER_CAL, tab, seg_chunks=2)
+    data, off, ln = OC.flatten(chans)
+    want = _dense(OC, OC.encode(data, off, ln, p))  # segments never span channels: blocks concatenate exactly
+    assert np.array_equal(got["payload"], want)
+    assert got["offs"][-1, 0] == len(want)
