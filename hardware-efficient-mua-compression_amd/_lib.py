@@ -49,6 +49,7 @@ PROTOTYPES = {
     "mh_synth_poisson": (_int, [_vp, _vp, _vp, _u32, _u64, _vp, _u64, _vp]),
     "mh_rebin": (_int, [_vp, _vp, _vp, _u32, _u64, _u32, _int, _vp, _vp, _vp]),
     "mh_deinterleave": (_int, [_vp, _u64, _u32, _vp, _vp, _vp]),
+    "mh_interleave": (_int, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "mh_sweep_create": (_int, [ct.POINTER(_vp), _vp, _vp, _u32, _vp, _u32]),
     "mh_sweep_destroy": (_int, [_vp]),
     "mh_sweep_info": (_int, [_vp, ct.POINTER(_u32), _vp]),

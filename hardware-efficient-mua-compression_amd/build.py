@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libmuahuff.so")
 SOURCES = ["csrc/muahuff.hip"]
-HEADERS = ["csrc/mh_kernels.hpp", "csrc/mh_device.hpp", "../include/muahuff.h"]
+HEADERS = ["csrc/mh_kernels.hpp", "csrc/mh_device.hpp", "csrc/mh_codec2.hpp", "csrc/mh_layout.hpp",
+           "../include/muahuff.h"]
 
 
 def stale():
@@ -31,6 +32,20 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=HERE)
     return SO
+
+
+def build_example(force=False):
+    """examples/abi_roundtrip: a plain-C client of include/muahuff.h (gcc, HIP runtime only)."""
+    src = os.path.join(ROOT, "examples", "abi_roundtrip.c")
+    exe = os.path.join(ROOT, "examples", "abi_roundtrip")
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) > max(os.path.getmtime(src), os.path.getmtime(SO)):
+        return exe
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(rocm, "include"), src, "-o", exe,
+                           "-L" + HERE, "-lmuahuff", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+                           "-Wl,-rpath,$ORIGIN/../" + os.path.basename(HERE), "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    return exe
 
 
 if __name__ == "__main__":

@@ -78,6 +78,22 @@ class ChannelSet:
         o, n = int(self.ch_off[i]), int(self.ch_len[i])
         return self.data[o:o + n]
 
+    def to_time_major(self):
+        """[T, C] uint8 device tensor, |CH1|CH2|...|CHN| per time step (mh_interleave); all
+        channels must have the same length."""
+        import ctypes as ct
+
+        from . import _lib
+        T = int(self.ch_len[0]) if self.C else 0
+        if not np.all(self.ch_len == np.uint64(T)):
+            raise ValueError("to_time_major needs channels of equal length")
+        out = torch.empty((T, self.C), dtype=torch.uint8, device=self.data.device)
+        d_off = torch.from_numpy(self.ch_off.astype(np.int64)).to(self.data.device)
+        _lib.check(_lib.lib().mh_interleave(ct.c_void_p(self.data.data_ptr()), ct.c_void_p(d_off.data_ptr()), T, self.C,
+                                            ct.c_void_p(out.data_ptr()),
+                                            ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
     def to_channels(self):
         host = self.data.cpu().numpy()
         return [host[int(o):int(o) + int(n)].copy() for o, n in zip(self.ch_off, self.ch_len)]

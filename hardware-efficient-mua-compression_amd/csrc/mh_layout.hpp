@@ -5,6 +5,7 @@
 //                    MATLAB histogram2 binning, Data/Load_and_bin_Sabes_store_as_mat_file.m:50-54):
 //                    a workgroup stages a contiguous 32 KiB span of one channel in LDS with
 //                    16-byte loads, then each thread sums its r bytes with v_sad_u8 on dwords.
+//   k_interleave     channel-major -> time-major, the inverse of k_deinterleave2
 //   k_deinterleave2  the same transposition as k_deinterleave with dword-only LDS traffic (below)
 //   k_deinterleave   time-major interleaved samples |CH1|CH2|...|CHN| per time step (the FPGA's
 //                    compression-phase input order, ref: FPGA implementation/README.md:31) ->
@@ -344,6 +345,77 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
                         tr2_store_partial(dst, o[k], th - tb * 16);
                     }
                 }
+            }
+        }
+    }
+}
+
+// k_interleave: the inverse of k_deinterleave2 (channel-major -> time-major [T][C]) with the same
+// tile, swizzle and byte transposes run the other way: 16-byte reads of 16 time steps of each of
+// 4 channels, transposed in registers into 16 dwords (4 channels of one time step each) for
+// LDS, then 128 contiguous bytes per time step written with 16-byte stores.
+__global__ __launch_bounds__(256) void k_interleave(const uint8_t *__restrict__ in, const uint64_t *in_off,
+                                                    uint64_t T, uint32_t C, uint32_t tpw,
+                                                    uint8_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kTr2T * (kTr2C / 4)];
+    const uint32_t c0 = blockIdx.y * kTr2C;
+    const uint32_t cw = C - c0 < (uint32_t)kTr2C ? C - c0 : (uint32_t)kTr2C;
+    const uint64_t ntiles = (T + kTr2T - 1) / kTr2T;
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * tpw; tile0 < ntiles; tile0 += (uint64_t)gridDim.x * tpw) {
+        const uint64_t tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
+        for (uint64_t tl = tile0; tl < tend; ++tl) {
+            const uint64_t t0 = tl * kTr2T;
+            const uint32_t th = T - t0 < (uint64_t)kTr2T ? (uint32_t)(T - t0) : (uint32_t)kTr2T;
+            __syncthreads();  // previous tile fully written out
+#pragma unroll 1
+            for (int uu = 0; uu < 2; ++uu) {
+                const uint32_t id = threadIdx.x + 256u * uu, tb = id & 15u, cg = id >> 4;
+                if (cg * 4 >= cw || tb * 16 >= th) continue;
+                const uint32_t nt = th - tb * 16 < 16u ? th - tb * 16 : 16u;
+                u32x4 x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = cg * 4 + k;
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    x[k] = z;
+                    if (c < cw) {
+                        const uint8_t *src = in + in_off[c0 + c] + t0 + tb * 16;
+                        x[k] = nt == 16 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(src))
+                                        : tr2_load_partial(src, nt);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {  // times 4m..4m+3 of the 4 channels -> one dword per time step
+                    const uint32_t a = x[0][m], b = x[1][m], c = x[2][m], e = x[3][m];
+                    const uint32_t t0_ = __builtin_amdgcn_perm(b, a, 0x05010400u);
+                    const uint32_t t1_ = __builtin_amdgcn_perm(e, c, 0x05010400u);
+                    const uint32_t t2_ = __builtin_amdgcn_perm(b, a, 0x07030602u);
+                    const uint32_t t3_ = __builtin_amdgcn_perm(e, c, 0x07030602u);
+                    const uint32_t d0 = __builtin_amdgcn_perm(t1_, t0_, 0x05040100u);
+                    const uint32_t d1 = __builtin_amdgcn_perm(t1_, t0_, 0x07060302u);
+                    const uint32_t d2 = __builtin_amdgcn_perm(t3_, t2_, 0x05040100u);
+                    const uint32_t d3 = __builtin_amdgcn_perm(t3_, t2_, 0x07060302u);
+                    const uint32_t r0 = tb * 16 + 4 * m, col = cg ^ (tb << 1);
+                    tile[(r0 + 0) * (kTr2C / 4) + (col ^ 0u)] = d0;
+                    tile[(r0 + 1) * (kTr2C / 4) + (col ^ 1u)] = d1;
+                    tile[(r0 + 2) * (kTr2C / 4) + (col ^ 2u)] = d2;
+                    tile[(r0 + 3) * (kTr2C / 4) + (col ^ 3u)] = d3;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t i = (uint32_t)j * 256 + threadIdx.x, row = i >> 3, q = (i & 7) * 16, q4 = (i & 7) * 4;
+                if (row >= th || q >= cw) continue;
+                const uint32_t sw = tr2_swz(row);
+                const uint32_t *r = tile + row * (kTr2C / 4);
+                const u32x4 v = {r[(q4 + 0) ^ sw], r[(q4 + 1) ^ sw], r[(q4 + 2) ^ sw], r[(q4 + 3) ^ sw]};
+                uint8_t *dst = out + (t0 + row) * C + c0 + q;
+                if (q + 16 <= cw)
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_u *>(dst));
+                else
+                    tr2_store_partial(dst, v, cw - q);
             }
         }
     }

@@ -743,6 +743,21 @@ int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, con
     return MH_OK;
 }
 
+int mh_interleave(const uint8_t *in, const uint64_t *in_off, uint64_t T, uint32_t C, uint8_t *out, void *stream)
+{
+    if (!in || !in_off || !out || C == 0) return fail(MH_ERR_ARG, "mh_interleave: bad argument");
+    if (T == 0) return MH_OK;
+    const uint32_t tpw = 4;
+    uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
+    if (bx > 0x7FFFFFFFull) bx = 0x7FFFFFFFull;
+    const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
+    if (by > 65535) return fail(MH_ERR_ARG, "mh_interleave: C=%u too large", C);
+    hipLaunchKernelGGL(mh::k_interleave, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, in_off, T, C,
+                       tpw, out);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
 int mh_sweep_destroy(mh_sweep *w)
 {
     if (!w) return MH_OK;

@@ -96,6 +96,8 @@ class StreamEncoder:
 
     @staticmethod
     def decode_block(c, device="cuda"):
-        """-> [Tb, C] time-major array of min(x, S-1)."""
-        chans = container_io.decompress(c, device=device).to_channels()
-        return np.stack(chans, axis=1) if chans else np.zeros((0, 0), np.uint8)
+        """-> [Tb, C] time-major array of min(x, S-1) (decoded and re-interleaved on the GPU)."""
+        cs = container_io.decompress(c, device=device)
+        if cs.C == 0:
+            return np.zeros((0, 0), np.uint8)
+        return cs.to_time_major().cpu().numpy()

@@ -16,7 +16,7 @@
  *     allocates and owns every buffer;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); device work is
  *     enqueued asynchronously on it and nothing in mh_measure/mh_encode/mh_decode/
- *     mh_compact/mh_synth_poisson/mh_rebin synchronises, allocates or frees, so they can
+ *     mh_compact/mh_synth_poisson/mh_rebin/mh_deinterleave/mh_interleave synchronises, allocates or frees, so they can
  *     be captured into a hipGraph;
  *   - a plan is bound to the device that was current when it was created and may be used
  *     from one stream at a time (it owns per-channel scratch tables).
@@ -177,6 +177,10 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
  * Channel c is written to out + out_off[c] (T bytes).  in, out, out_off: device. */
 int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, const uint64_t *out_off,
                     void *stream);
+/* The inverse: channel c = T bytes at in + in_off[c]  ->  out[t*C + c] (what a decoder hands back
+ * to a consumer of the implant-order stream).  in, in_off, out: device. */
+int mh_interleave(const uint8_t *in, const uint64_t *in_off, uint64_t T, uint32_t C, uint8_t *out,
+                  void *stream);
 
 /* ---- fused sweep histograms (all design points from ONE pass over the data) --------------
  * The two BR scripts loop S = 2..10 and histogram sizes 2^h (get_BR_with_approx_sort.py:107,157)

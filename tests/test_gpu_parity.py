@@ -333,6 +333,19 @@ def test_deinterleave_time_major_stream(mh, T, C):
         assert np.array_equal(got[c], x[:, c]), c
 
 
+@pytest.mark.parametrize("T,C", [(1, 1), (255, 3), (256, 128), (1000, 96), (4097, 130), (777, 257), (2048, 1024),
+                                 (15, 4), (16, 5), (3000, 143)])
+def test_interleave_is_the_inverse_layout(mh, T, C):
+    rng = np.random.RandomState(3 * T + C)
+    x = rng.randint(0, 256, size=(T, C)).astype(np.uint8)
+    cs = _cs(mh, [x[:, c].copy() for c in range(C)])
+    got = cs.to_time_major()
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), x)
+    back = mh.container.ChannelSet.from_time_major(got)
+    assert torch.equal(back.data[:cs.data.numel() - 16], cs.data[:cs.data.numel() - 16])
+
+
 def test_compress_save_load_decompress(mh, tmp_path):
     from muahuff import container_io as cio
     rng = np.random.RandomState(21)
@@ -522,3 +535,15 @@ def test_many_channels_and_extreme_parameters(mh):
         want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host), nthreads=8)
         assert np.array_equal(out.cpu().numpy(), want)
         plan.close()
+
+
+def test_plain_c_client_of_the_abi(mh):
+    """The C ABI without Python or torch in the loop: examples/abi_roundtrip.c allocates with the
+    HIP runtime, runs synth -> measure -> encode -> decode and checks decode == clip(x) and
+    bits == SCLV . histogram on the host."""
+    import subprocess
+    b = __import__("importlib").import_module("hardware-efficient-mua-compression_amd.build")
+    exe = b.build_example()
+    for args in (["24", "100003"], ["3", "17"], ["130", "40000"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.startswith("OK "), (args, r.stdout, r.stderr)

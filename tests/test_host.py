@@ -157,3 +157,16 @@ def test_missing_library_fails_loudly(tmp_path):
     env = dict(os.environ, MUAHUFF_LIB=str(tmp_path / "nope.so"), PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert "LOUD True" in out.stdout, out.stdout + out.stderr
+
+
+def test_plain_c_client_builds_and_fails_loudly_without_gpu():
+    """examples/abi_roundtrip.c: include/muahuff.h is valid C11 and links from gcc; with no
+    device the very first call reports MH_ERR_NO_DEVICE (exit 3), it does not fall back."""
+    import subprocess
+    import torch
+    b = __import__("importlib").import_module("hardware-efficient-mua-compression_amd.build")
+    exe = b.build_example()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "no HIP device" in r.stderr, r.stderr

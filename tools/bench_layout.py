@@ -65,3 +65,6 @@ cs2 = container.ChannelSet.empty([T2] * C2)
 o2 = torch.from_numpy(cs2.ch_off.astype(np.int64)).cuda()
 ms = timed(lambda: lib.mh_deinterleave(vp(x.data_ptr()), T2, C2, vp(cs2.data.data_ptr()), vp(o2.data_ptr()), None), 3)
 print("deinterleave %d x %d: %.3f ms (%.2f TB/s read+write)" % (T2, C2, ms, 2 * T2 * C2 / ms / 1e9))
+y = torch.empty_like(x)
+ms = timed(lambda: lib.mh_interleave(vp(cs2.data.data_ptr()), vp(o2.data_ptr()), T2, C2, vp(y.data_ptr()), None), 3)
+print("interleave   %d x %d: %.3f ms (%.2f TB/s read+write)  roundtrip %s" % (T2, C2, ms, 2 * T2 * C2 / ms / 1e9, bool(torch.equal(x, y))))
