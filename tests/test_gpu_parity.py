@@ -547,3 +547,39 @@ def test_plain_c_client_of_the_abi(mh):
     for args in (["24", "100003"], ["3", "17"], ["130", "40000"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and r.stdout.startswith("OK "), (args, r.stdout, r.stderr)
+
+
+def test_error_paths_with_a_device(mh):
+    """Argument and capacity errors are reported through codes + mh_last_error, and a dense
+    buffer that is too small is never written past (the caller sees the needed size)."""
+    import ctypes as ct
+    lib, L = mh._lib.lib(), mh._lib
+    rng = np.random.RandomState(1)
+    cs = _cs(mh, [rng.randint(0, 4, size=50000).astype(np.uint8) for _ in range(4)])
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 1, mh.WIN_AFTER_CAL, helpers.sclv_tables()[3])
+    e = plan.alloc_encoded()
+    vp = ct.c_void_p
+    ptr = lambda t: vp(t.data_ptr())
+    rc = lib.mh_encode(plan._h, ptr(cs.data), ptr(e.payload), plan.payload_cap_words - 1, ptr(e.seg_words),
+                       ptr(e.ch_bits), None, None, None, None)
+    assert rc == L.ERR_CAPACITY and b"plan needs" in lib.mh_last_error()
+    rc = lib.mh_encode(plan._h, None, ptr(e.payload), plan.payload_cap_words, ptr(e.seg_words), ptr(e.ch_bits),
+                       None, None, None, None)
+    assert rc == L.ERR_ARG
+    rc = lib.mh_decode(plan._h, ptr(e.payload), None, None, None, ptr(cs.data), None)
+    assert rc == L.ERR_ARG
+    rc = lib.mh_rebin(ptr(cs.data), ptr(cs.data), ptr(cs.data), 4, 50000, 5000, 1, ptr(cs.data), ptr(cs.data), None)
+    assert rc == L.ERR_ARG and b"4096" in lib.mh_last_error()
+    with pytest.raises(mh.MuaHuffError):
+        mh.codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 7, mh.WIN_AFTER_CAL, helpers.sclv_tables()[3])  # mode 7
+    # compact into a buffer that is too small: total_words still says what is needed, the guard words stay
+    plan.encode(cs.data, out=e)
+    total = int(e.seg_words.sum().item())
+    small = torch.full((total // 2 + 64,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    off = torch.zeros(plan.n_segments, dtype=torch.int64, device="cuda")
+    tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    L.check(lib.mh_compact(plan._h, ptr(e.payload), ptr(e.seg_words), ptr(small), total // 2, ptr(off), ptr(tot), None))
+    torch.cuda.synchronize()
+    assert int(tot.item()) == total
+    assert bool((small[total // 2:] == 0x5A5A5A5A).all())
+    plan.close()
