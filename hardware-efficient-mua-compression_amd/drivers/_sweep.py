@@ -114,8 +114,10 @@ def split_indices(n_per_dataset, base, how_many_sabes, train_percentage):
     return train, val
 
 
-def evaluate(dev, train_idx, val_idx, S, table, BP, approx):
-    """One (CV, BP, S) cell -> the dict the reference pickles (:138-334)."""
+def evaluate(dev, train_idx, val_idx, S, table, BP, approx, python_floats=False):
+    """One (CV, BP, S) cell -> the dict the reference pickles (:138-334).
+    python_floats: store each BR as a Python float instead of np.float64 (same bits; a list of
+    1e6 np.float64 scalars takes ~1.7 s to pickle, the same list of floats 0.02 s)."""
     from ..codec import bit_rate
     S = int(S)
     sclvs = np.array([np.asarray(r, dtype=np.float64) for r in table], dtype=object)  # :125
@@ -153,7 +155,8 @@ def evaluate(dev, train_idx, val_idx, S, table, BP, approx):
             # (exact in any order), the two divisions are element-wise float64 as in the reference
             n = post.sum(axis=0)
             bits = (cur[k, :] * post.T).sum(axis=1)
-            per_hist.append(list(bit_rate(bits, n, BP)))
+            br = bit_rate(bits, n, BP)
+            per_hist.append(br.tolist() if python_floats else list(br))
         stored_BRs.append(per_hist)
         if len(sclvs) != 1:  # :310-316 drop the encoder whose removal hurts the training set least
             cost = np.zeros(len(sclvs))
@@ -167,8 +170,10 @@ def evaluate(dev, train_idx, val_idx, S, table, BP, approx):
 
 
 def run(root_directory, approx, nb_CV_iterations=30, how_many_channels_Sabes=2000, train_percentage=50,
-        S_values=range(2, 11), write=True, verbose=True, fused=True):
+        S_values=range(2, 11), write=True, verbose=True, fused=True, python_floats=False):
     """Whole sweep.  Returns {(S, BP, CV): result dict}; writes the pickles when `write`.
+    python_floats=True writes the bit rates as Python floats (identical values, ~90x faster
+    pickling; the default keeps the reference's np.float64 elements).
     fused=True: one GPU pass per bin period (mh_sweep_run); fused=False: one mh_measure per
     (CV, S, h) -- same results, kept as a cross-check."""
     d = read_directories(root_directory)
@@ -185,7 +190,7 @@ def run(root_directory, approx, nb_CV_iterations=30, how_many_channels_Sabes=200
             for S in S_values:
                 if verbose:
                     print("BP: " + str(BP) + "; S: " + str(int(S)))
-                res = evaluate(dev, train_idx, val_idx, int(S), tabs[int(S)], BP, approx)
+                res = evaluate(dev, train_idx, val_idx, int(S), tabs[int(S)], BP, approx, python_floats)
                 out[(int(S), BP, int(cv))] = res
                 if write:
                     os.makedirs(results_dir, exist_ok=True)

@@ -19,10 +19,12 @@ def main(argv=None):
     ap.add_argument("--root", required=True)
     ap.add_argument("--cv", type=int, default=30, help="nb_CV_iterations (the reference runs 1..cv-1)")
     ap.add_argument("--seed", type=int, default=None, help="np.random.seed for a reproducible channel split")
+    ap.add_argument("--python-floats", action="store_true",
+                    help="store bit rates as Python floats (same values, ~90x faster to pickle than np.float64 scalars)")
     a = ap.parse_args(argv)
     if a.seed is not None:
         np.random.seed(a.seed)
-    run(a.root, nb_CV_iterations=a.cv)
+    run(a.root, nb_CV_iterations=a.cv, python_floats=a.python_floats)
 
 
 if __name__ == "__main__":

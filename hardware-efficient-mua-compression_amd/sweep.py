@@ -81,8 +81,8 @@ class SweepHist:
     # ---- host arithmetic ------------------------------------------------------------------
     def _at(self, idx, pos):
         """prefix histogram [len(idx), 10] at sample position pos[i] of channel idx[i]"""
-        b = self.bounds[idx]
-        j = np.array([np.searchsorted(b[i], pos[i], side="left") for i in range(len(idx))], dtype=np.int64)
+        b = self.bounds[idx]  # [n, intervals + 1], ascending per row
+        j = (b < np.asarray(pos, dtype=b.dtype)[:, None]).sum(axis=1)  # row-wise searchsorted(side="left")
         return self.cum[idx, j, :]
 
     @staticmethod

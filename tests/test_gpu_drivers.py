@@ -55,6 +55,21 @@ def test_sweep_driver_is_bit_exact(tmp_path, tag, fused):
         assert isinstance(r["stored_all_var_BRs"][0][0][0], np.float64)
 
 
+def test_sweep_driver_python_floats_option(tmp_path):
+    """python_floats=True changes the element type only (fast pickling), never a bit of a value."""
+    from muahuff.drivers import get_BR_with_approx_sort
+    z, params = helpers.sweep()
+    root, res_a, _ = _tree(tmp_path, z)
+    np.random.seed(params["seed"])
+    out = get_BR_with_approx_sort.run(root, nb_CV_iterations=params["nb_CV_iterations"],
+                                      how_many_channels_Sabes=params["how_many_channels_Sabes"], verbose=False,
+                                      python_floats=True)
+    for (S, BP, cv), res in out.items():
+        key = "approx/S%d_BP%d_CV%d/" % (S, BP, cv)
+        assert type(res["stored_all_var_BRs"][0][0][0]) is float
+        assert helpers.same_float(np.array(res["stored_all_var_BRs"], dtype=np.float64), z[key + "BRs"]), key
+
+
 def test_chosen_system_driver(tmp_path):
     from muahuff.drivers import test_chosen_system as tcs
     z, _ = helpers.sweep()

@@ -28,6 +28,20 @@ with tempfile.TemporaryDirectory() as tmp:
     with open(os.path.join(fmt, "all_binned_data_train.pkl"), "wb") as f:
         pickle.dump({"all_binned_data": [[chans[:half], chans[half:]]], "bin_vector": [50],
                      "datasets": ["Flint", "Sabes"]}, f)
+    if os.environ.get("PROFILE"):
+        import cProfile
+        import pstats
+        np.random.seed(1)
+        get_BR_with_approx_sort.run(root, nb_CV_iterations=2, verbose=False, fused=True)  # warm-up
+        pr = cProfile.Profile()
+        np.random.seed(1)
+        t0 = time.perf_counter()
+        pr.enable()
+        get_BR_with_approx_sort.run(root, nb_CV_iterations=int(os.environ.get("CV", "4")), verbose=False, fused=True)
+        pr.disable()
+        print("profiled run: %.3f s" % (time.perf_counter() - t0))
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+        sys.exit(0)
     for fused in (True, False, True):
         np.random.seed(1)
         t0 = time.perf_counter()
