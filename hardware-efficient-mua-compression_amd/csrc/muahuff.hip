@@ -104,7 +104,7 @@ struct mh_plan {
     uint32_t dec_K = 4;  // symbols per decode-table lookup
     uint32_t dec_NR = 32; // staging registers per lane of the hybrid decoder
     uint64_t *d_scan = nullptr;  // block sums of mh_compact's segment scan
-    uint2 *d_dtab2 = nullptr;  // sized for 8-byte entries; K <= 2 plans use half of it
+    uint2 *d_dtab2 = nullptr;  // 4-symbol decode tables (dec_K == 4 plans only)
 };
 
 struct mh_sweep {
@@ -115,6 +115,16 @@ struct mh_sweep {
     uint32_t *d_tile_ch = nullptr, *d_tile_n = nullptr, *d_tile_slot = nullptr;
     unsigned long long *d_scratch = nullptr;
 };
+
+// device operations run on the plan's device: its tables live there
+static int check_device(const mh_plan *p, const char *who)
+{
+    int d = -1;
+    MH_HIP(hipGetDevice(&d));
+    if (d != p->device)
+        return fail(MH_ERR_ARG, "%s: plan was created on device %d, the current device is %d", who, p->device, d);
+    return MH_OK;
+}
 
 static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
                             uint8_t *peak, uint8_t *enc, hipStream_t st, unsigned long long *zero_hist,
@@ -497,6 +507,7 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
                uint8_t *skipped, void *stream)
 {
     if (!p || !data) return fail(MH_ERR_ARG, "mh_measure: NULL argument");
+    if (int rc_ = check_device(p, "mh_measure")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
     int rc = launch_calibrate(p, data, cutoff, cal_hist, pk, en, st, p->d_hist, nullptr, nullptr);
@@ -572,6 +583,7 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
 {
     if (!p || !data || !payload || !seg_words || !ch_bits)
         return fail(MH_ERR_ARG, "mh_encode: NULL argument");
+    if (int rc_ = check_device(p, "mh_encode")) return rc_;
     if (payload_cap_words < p->info.payload_cap_words)
         return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
                     (unsigned long long)payload_cap_words,
@@ -590,6 +602,7 @@ int mh_encode_preset(mh_plan *p, const uint8_t *data, const uint8_t *peak, const
 {
     if (!p || !data || !peak || !enc || !payload || !seg_words || !ch_bits)
         return fail(MH_ERR_ARG, "mh_encode_preset: NULL argument");
+    if (int rc_ = check_device(p, "mh_encode_preset")) return rc_;
     if (payload_cap_words < p->info.payload_cap_words)
         return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
                     (unsigned long long)payload_cap_words,
@@ -606,6 +619,7 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
               const uint8_t *enc, uint8_t *out, void *stream)
 {
     if (!p || !payload || !peak || !enc || !out) return fail(MH_ERR_ARG, "mh_decode: NULL argument");
+    if (int rc_ = check_device(p, "mh_decode")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     if (p->info.n_segments == 0) return MH_OK;
     mh::DecArgs a;
@@ -650,6 +664,7 @@ int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, u
 {
     if (!p || !payload || !seg_words || !dense || !dense_off || !total_words)
         return fail(MH_ERR_ARG, "mh_compact: NULL argument");
+    if (int rc_ = check_device(p, "mh_compact")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t nseg = p->info.n_segments;
     const uint64_t nblocks = (nseg + mh::kScanBlock - 1) / mh::kScanBlock;
