@@ -43,8 +43,9 @@ def compress(channels, S=3, hist_bits=6, approx=True, sclv_rows=None, path=None)
     return c
 
 
-def decompress(c_or_path):
-    """-> list of uint8 arrays: min(x, S-1) after the calibration window, zeros before it."""
+def decompress(c_or_path, channels=None):
+    """-> list of uint8 arrays: min(x, S-1) after the calibration window, zeros before it.
+    channels: optional list of channel indices to decode (random access through the directory)."""
     from . import container_io
     c = container_io.load(c_or_path) if isinstance(c_or_path, (str, bytes)) or hasattr(c_or_path, "__fspath__") else c_or_path
-    return container_io.decompress(c).to_channels()
+    return container_io.decompress(c, channels=channels).to_channels()

@@ -130,26 +130,67 @@ def compress(cs, S, h, mode, sclv, window=None, seg_chunks=2):
     return c
 
 
-def decompress(c, device="cuda"):
+def segments_per_channel(ch_len, h, window, seg_chunks):
+    """Number of directory entries of each channel: the window rule of include/muahuff.h applied
+    to the channel length, cut into segments of seg_chunks chunks (the planner's layout)."""
+    from . import CHUNK, WIN_AFTER_CAL, WIN_FULL, WIN_REF_HALF, WIN_REF_HALF_TRUNC
+    T = np.asarray(ch_len, dtype=np.int64)
+    c = np.minimum(np.int64(1) << int(h), T)
+    e = c + T // 2
+    if window == WIN_REF_HALF:
+        n = np.where(e > T, 0, e - c)
+    elif window == WIN_REF_HALF_TRUNC:
+        n = np.minimum(e, T) - c
+    elif window == WIN_AFTER_CAL:
+        n = T - c
+    elif window == WIN_FULL:
+        n = T
+    else:
+        raise ValueError("unknown window rule %r" % (window,))
+    seg = int(seg_chunks) * CHUNK
+    return (n + seg - 1) // seg
+
+
+def decompress(c, device="cuda", channels=None):
     """Inverse of compress(): a ChannelSet whose windows hold min(x, S-1) (bytes outside the
-    encoded windows are zero)."""
+    encoded windows are zero).  channels: optional list of channel indices -- only their segments
+    are uploaded and decoded (the directory gives random access per channel); the returned set
+    holds them in the order given."""
     import torch
 
     from . import codec
     from .container import ChannelSet
     hd = c.header
-    cs = ChannelSet.empty([int(n) for n in c.ch_len], device=device)
+    nseg_ch = segments_per_channel(c.ch_len, hd["h"], hd["window"], hd["seg_chunks"])
+    if int(nseg_ch.sum()) != len(c.seg_words):
+        raise ValueError("container directory does not match its header")
+    seg_words, payload, peak, enc, skipped, ch_bits, ch_len = (c.seg_words, c.payload, c.peak, c.enc, c.skipped,
+                                                                c.ch_bits, c.ch_len)
+    if channels is not None:
+        sel = np.asarray(channels, dtype=np.int64)
+        if sel.size and (sel.min() < 0 or sel.max() >= len(c.ch_len)):
+            raise IndexError("channel index out of range")
+        first = np.concatenate([[0], np.cumsum(nseg_ch)]).astype(np.int64)       # channel -> first segment
+        off = np.concatenate([[0], np.cumsum(c.seg_words)]).astype(np.int64)    # segment -> first word
+        segs = np.concatenate([np.arange(first[i], first[i + 1]) for i in sel]) if sel.size else np.zeros(0, np.int64)
+        payload = (np.concatenate([c.payload[off[s]:off[s + 1]] for s in segs]) if segs.size
+                   else np.zeros(0, np.uint32))
+        seg_words = c.seg_words[segs]
+        peak, enc, skipped, ch_bits, ch_len = c.peak[sel], c.enc[sel], c.skipped[sel], c.ch_bits[sel], c.ch_len[sel]
+    cs = ChannelSet.empty([int(n) for n in ch_len], device=device)
+    if len(ch_len) == 0:
+        return cs
     plan = codec.Plan(cs.ch_off, cs.ch_len, hd["S"], hd["h"], hd["mode"], hd["window"],
                       np.array(hd["sclv"], np.uint8), seg_chunks=hd["seg_chunks"])
-    if plan.n_segments != len(c.seg_words):
+    if plan.n_segments != len(seg_words):
         raise ValueError("container directory does not match its header")
     dev = cs.data.device
-    pay = torch.zeros(c.payload.size + 4, dtype=torch.int32, device=dev)
-    pay[:c.payload.size] = torch.from_numpy(c.payload.view(np.int32)).to(dev)
-    seg_off = np.concatenate([[0], np.cumsum(c.seg_words)[:-1]]).astype(np.int64) if len(c.seg_words) else np.zeros(1, np.int64)
-    e = codec.Encoded(pay, torch.from_numpy(c.seg_words.astype(np.int64)).to(dev),
-                      torch.from_numpy(c.ch_bits.astype(np.int64)).to(dev), torch.from_numpy(c.peak).to(dev),
-                      torch.from_numpy(c.enc).to(dev), torch.from_numpy(c.skipped).to(dev),
+    pay = torch.zeros(payload.size + 4, dtype=torch.int32, device=dev)
+    pay[:payload.size] = torch.from_numpy(np.ascontiguousarray(payload).view(np.int32)).to(dev)
+    seg_off = np.concatenate([[0], np.cumsum(seg_words)[:-1]]).astype(np.int64) if len(seg_words) else np.zeros(1, np.int64)
+    e = codec.Encoded(pay, torch.from_numpy(seg_words.astype(np.int64)).to(dev),
+                      torch.from_numpy(ch_bits.astype(np.int64)).to(dev), torch.from_numpy(np.ascontiguousarray(peak)).to(dev),
+                      torch.from_numpy(np.ascontiguousarray(enc)).to(dev), torch.from_numpy(np.ascontiguousarray(skipped)).to(dev),
                       torch.from_numpy(seg_off).to(dev), True)
     plan.decode(e, cs.data)
     torch.cuda.synchronize()

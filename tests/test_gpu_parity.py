@@ -583,3 +583,24 @@ def test_error_paths_with_a_device(mh):
     assert int(tot.item()) == total
     assert bool((small[total // 2:] == 0x5A5A5A5A).all())
     plan.close()
+
+
+def test_random_access_decompress_of_selected_channels(mh):
+    """The per-channel directory gives random access: decoding a subset equals the same channels of
+    the full decode, for every window rule (skipped and empty-window channels included)."""
+    from muahuff import container_io as cio
+    rng = np.random.RandomState(21)
+    lens = [5, 70000, 33, 16384 + 64, 100, 40001, 64, 65, 200000, 3]
+    chans = _channels(rng, lens)
+    cs = _cs(mh, chans)
+    for S, h, mode, window in ((3, 6, 1, 0), (5, 6, 1, 2), (10, 3, 0, 1), (4, 8, 1, 3)):
+        c = cio.compress(cs, S, h, mode, helpers.sclv_tables()[S], window=window)
+        assert int(cio.segments_per_channel(c.ch_len, h, window, 2).sum()) == len(c.seg_words)
+        full = cio.decompress(c).to_channels()
+        for sel in ([1], [8, 0, 5], [9, 2, 7, 6, 4, 3], list(range(10))[::-1], []):
+            got = cio.decompress(c, channels=sel).to_channels()
+            assert len(got) == len(sel)
+            for g, i in zip(got, sel):
+                assert np.array_equal(g, full[i]), (S, window, i)
+        with pytest.raises(IndexError):
+            cio.decompress(c, channels=[10])
