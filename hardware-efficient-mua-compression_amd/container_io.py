@@ -1,4 +1,4 @@
-"""Wire / file format of a compressed channel set (format revision 1), and the two calls that
+"""Wire / file format of a compressed channel set (format revision 2), and the two calls that
 make the codec usable end to end: compress() and decompress().
 
 The reference never serialises a bitstream; this container is the
@@ -23,7 +23,7 @@ from dataclasses import dataclass
 import numpy as np
 
 MAGIC = b"MUAHUFF1"
-FORMAT_REVISION = 1
+FORMAT_REVISION = 2
 
 
 @dataclass

@@ -63,11 +63,17 @@ __device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src,
     const uint32_t P = incl - tot;
     const uint32_t B = __shfl(incl, 63, 64);
     const uint32_t nw = (B + 31) >> 5;
-    const uint32_t other = __shfl_down(tot, 1, 64);
-    if (!(lane & 1)) gdst[lane >> 1] = tot | (other << 16);
-    uint32_t *gpay = gdst + kHdrWords;
+    const uint32_t mn = wave_min(tot), hwid = hdr_width(wave_max(tot) - mn), hw = hdr_words(hwid);
+    uint32_t *gpay = gdst + hw;
+    if ((uint32_t)lane < hw) gdst[lane] = lane == 0 ? (mn | (hwid << 12)) : 0u;
     for (uint32_t i = lane; i < nw; i += 64) gpay[i] = 0;
     __threadfence();  // the zeros are at L2 before any atomic below
+    if (hwid) {
+        const uint32_t fb = 16u + (uint32_t)lane * hwid;
+        const uint64_t f = (uint64_t)(tot - mn) << (fb & 31);
+        atomicOr(&gdst[fb >> 5], (uint32_t)f);
+        if ((uint32_t)(f >> 32)) atomicOr(&gdst[(fb >> 5) + 1], (uint32_t)(f >> 32));
+    }
     uint32_t pos = P;
 #pragma unroll 1
     for (int k = 0; k < kRows; ++k) {
@@ -84,7 +90,7 @@ __device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src,
             }
     }
     __threadfence();
-    return make_uint2(kHdrWords + nw, B);
+    return make_uint2(hw + nw, B);
 }
 
 // LC: 0 maxlen<=2 (flush check per piece), 1 maxlen<=4 (per 2 dwords), 2 maxlen<=8 (per dword),
@@ -127,7 +133,7 @@ __device__ __forceinline__ u32x4 load_row(const uint8_t *p)
 // buf[64,96)  room so that the 32-word chunk header always fits below R
 // R = buf+96  staging AND image area, 64*cap dwords:
 //   staging: lane l = 16*g + s keeps its j-th spilled dword at R[g*16*cap + j*16 + s]
-//   image:   header at buf[pend .. pend+32), payload right behind it, growing upwards.
+//   image:   header at buf[pend .. pend+hw), hw <= 25 words, payload right behind it, growing upwards.
 // The merge walks the four 16-lane groups in order.  A group's staged dwords (<= 16*cap) are
 // first pulled into registers by all 64 lanes (cap/4 each), then ORed into the payload.  The
 // payload written through group g ends at most at buf[pend+32 + 16*(g+1)*cap) <= R + 16*(g+1)*cap,
@@ -153,8 +159,16 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
     const uint32_t B = __shfl(incl, 63, 64);
     const uint32_t nw = (B + 31) >> 5;
     uint32_t *hdr = buf + pend;
-    uint32_t *pay = hdr + kHdrWords;
-    reinterpret_cast<uint16_t *>(hdr)[lane] = (uint16_t)tot;
+    const uint32_t mn = wave_min(tot), hwid = hdr_width(wave_max(tot) - mn), hw = hdr_words(hwid);
+    uint32_t *pay = hdr + hw;  // hw <= 25 < kHdrWords: the image starts no higher than before
+    if ((uint32_t)lane < hw) hdr[lane] = lane == 0 ? (mn | (hwid << 12)) : 0u;
+    MH_WAVE_SYNC();
+    if (hwid) {
+        const uint32_t fb = 16u + (uint32_t)lane * hwid;
+        const uint64_t f = (uint64_t)(tot - mn) << (fb & 31);
+        atomicOr(&hdr[fb >> 5], (uint32_t)f);
+        if ((uint32_t)(f >> 32)) atomicOr(&hdr[(fb >> 5) + 1], (uint32_t)(f >> 32));
+    }
     const uint32_t *R = buf + 96;
     const int sl = lane & 15, jq = lane >> 4;
     uint32_t zeroed = 0;  // payload words [0, zeroed) are initialised
@@ -187,7 +201,7 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
         MH_WAVE_SYNC();
     }
     // only whole, 256-byte-aligned blocks go to HBM (16 B per lane, non-temporal); the rest waits
-    const uint32_t total = pend + kHdrWords + nw;
+    const uint32_t total = pend + hw + nw;
     const uint32_t nflush = total & ~63u;
     if (ABL < 1)
         for (uint32_t i = lane * 4; i < nflush; i += 256)
@@ -201,7 +215,7 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
     MH_WAVE_SYNC();
     dst += nflush;
     pend = tail;
-    words = kHdrWords + nw;
+    words = hw + nw;
     bits = B;
 }
 
@@ -490,15 +504,19 @@ __host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W, uint32_t K)
 struct ChunkHdr {
     uint32_t P;   // this lane's sub-stream starts at bit P of the chunk payload
     uint32_t nw;  // payload words of the chunk
+    uint32_t hw;  // header words of the chunk (1..25)
 };
 
-__device__ __forceinline__ ChunkHdr scan_header(uint32_t hw, int lane)
+// hw32: word (lane & 31) of the chunk (a full chunk is longer than 32 words)
+__device__ __forceinline__ ChunkHdr scan_header(uint32_t hw32, int lane)
 {
-    const uint32_t len = (hw >> (16 * (lane & 1))) & 0xFFFFu;
+    uint32_t wid;
+    const uint32_t len = hdr_len_from_wave(hw32, lane, wid);
     const uint32_t incl = wave_scan_incl(len, lane);
     ChunkHdr h;
     h.P = incl - len;
     h.nw = (__shfl(incl, 63, 64) + 31) >> 5;
+    h.hw = hdr_words(wid);
     return h;
 }
 
@@ -660,36 +678,37 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
     const uint32_t rem = (uint32_t)(n % kChunk);
     if (nfull) {
         uint32_t R[NR];
-        ChunkHdr cur = scan_header(in[lane >> 1], lane);
-        const uint32_t *pay = in + kHdrWords;
+        ChunkHdr cur = scan_header(in[lane & 31], lane);
+        const uint32_t *pay = in + cur.hw;
         uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
 #pragma unroll
         for (int j = 0; j < NR; ++j)
             if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];  // reads <= 3 words of slack
         uint32_t hw_next = 0;
-        if (nfull > 1) hw_next = pay[cur.nw + (lane >> 1)];
+        if (nfull > 1) hw_next = pay[cur.nw + (lane & 31)];
         for (uint32_t c = 0; c < nfull; ++c) {
 #pragma unroll
             for (int j = 0; j < NR; ++j)  // payload(c): registers -> LDS
                 if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
             const ChunkHdr hc = cur;
-            const uint32_t *pay_c = pay;
+            const uint32_t *chunk_c = pay - cur.hw;  // first header word of chunk c
             const bool staged = ns != 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
-                pay = pay + cur.nw + kHdrWords;
+                const uint32_t *nextc = pay + cur.nw;  // chunk c+1
                 cur = scan_header(hw_next, lane);
+                pay = nextc + cur.hw;
                 ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
                     if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];
-                if (c + 2 < nfull) hw_next = pay[cur.nw + (lane >> 1)];
+                if (c + 2 < nfull) hw_next = pay[cur.nw + (lane & 31)];
             }
             if (staged)
                 decode_staged_chunk<K, M, RL, HY>(hc, tab, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
             else
-                decode_chunk<3, true>(pay_c - kHdrWords, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
+                decode_chunk<3, true>(chunk_c, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }

@@ -66,4 +66,48 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane)
     return v;
 }
 
+// ---- chunk header, format revision 2 ---------------------------------------------------------
+//   bits [0,12)  min  = shortest sub-stream length of the chunk (<= 256 * 9)
+//   bits [12,16) w    = bits needed for (longest - shortest), 0..12
+//   then 64 fields of w bits (sub-stream length - min), LSB-first from bit 16;
+//   header words = ceil((16 + 64 w) / 32) = 1..25 (kHdrWords = 32 stays the bound slots are sized by)
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t t = __shfl_xor(v, d, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t t = __shfl_xor(v, d, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__host__ __device__ __forceinline__ uint32_t hdr_words(uint32_t w) { return (16u + 64u * w + 31u) >> 5; }
+
+// field width for sub-stream lengths spanning `range` = longest - shortest
+__device__ __forceinline__ uint32_t hdr_width(uint32_t range) { return range ? 32u - (uint32_t)__builtin_clz(range) : 0u; }
+
+// Sub-stream length of `lane` from the first 32 words of a chunk, lane i holding word i & 31
+// (a full chunk is always longer than 32 words, so that load never leaves the chunk).
+// Returns the length; w_out = field width of this chunk.
+__device__ __forceinline__ uint32_t hdr_len_from_wave(uint32_t word, int lane, uint32_t &w_out)
+{
+    const uint32_t w0 = __shfl(word, 0, 64);
+    const uint32_t mn = w0 & 0xFFFu, w = (w0 >> 12) & 15u;
+    const uint32_t fb = 16u + (uint32_t)lane * w;
+    const uint32_t lo = __shfl(word, (int)(fb >> 5), 64), hi = __shfl(word, (int)((fb >> 5) + 1) & 31, 64);
+    const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+    w_out = w;
+    return mn + ((uint32_t)(v >> (fb & 31)) & ((1u << w) - 1u));
+}
+
 }  // namespace mh

@@ -291,12 +291,20 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in
                                                  const uint8_t *dtab, uint32_t mask,
                                                  uint8_t *__restrict__ out, int lane)
 {
-    const uint32_t hw = in[lane >> 1];
-    const uint32_t len = (hw >> (16 * (lane & 1))) & 0xFFFFu;
+    // header (format revision 2, mh_device.hpp): two dependent reads, only words of this chunk
+    const uint32_t w0 = in[0];
+    const uint32_t mn = w0 & 0xFFFu, hwid = (w0 >> 12) & 15u, hw = hdr_words(hwid);
+    uint32_t len = mn;
+    if (hwid) {
+        const uint32_t fb = 16u + (uint32_t)lane * hwid;
+        uint64_t v = in[fb >> 5];
+        if ((fb & 31) + hwid > 32) v |= (uint64_t)in[(fb >> 5) + 1] << 32;
+        len += (uint32_t)(v >> (fb & 31)) & ((1u << hwid) - 1u);
+    }
     const uint32_t incl = wave_scan_incl(len, lane);
     const uint32_t P = incl - len;
     const uint32_t B = __shfl(incl, 63, 64);
-    const uint32_t *pay = in + kHdrWords;
+    const uint32_t *pay = in + hw;
     uint32_t wi = P >> 5, bp = P & 31;
     // 64-bit window + one word of read-ahead; reads may run <= 3 words past the chunk
     uint64_t buf = (uint64_t)pay[wi] | ((uint64_t)pay[wi + 1] << 32);
@@ -335,7 +343,7 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in
                 if (i < cnt) out[base + i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
         }
     }
-    return kHdrWords + ((B + 31) >> 5);
+    return hw + ((B + 31) >> 5);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MH_VERSION 100 /* 0.1.0 ; container format revision 1 */
+#define MH_VERSION 101 /* 0.1.1 ; container format revision 2 */
 
 /* ---- error codes -------------------------------------------------------------------- */
 #define MH_OK 0
@@ -43,14 +43,16 @@ extern "C" {
 #define MH_ERR_HIP (-5)           /* a HIP runtime call failed (message has the HIP error) */
 #define MH_ERR_NO_DEVICE (-6)     /* no gfx950 device visible: there is NO CPU fallback */
 
-/* ---- container geometry (format revision 1; the reference has no bitstream, so this is
+/* ---- container geometry (format revision 2; the reference has no bitstream, so this is
  *      build-defined -- see DESIGN.md "Container") ----------------------------------- */
 #define MH_PIECE 16                        /* samples per piece (one 16-byte vector)          */
 #define MH_LANES 64                        /* sub-streams per chunk = lanes of a wavefront    */
 #define MH_ROWS 16                         /* pieces per sub-stream                           */
 #define MH_SUB (MH_PIECE * MH_ROWS)        /* 256 samples per sub-stream                      */
 #define MH_CHUNK (MH_SUB * MH_LANES)       /* 16384 samples per chunk                         */
-#define MH_HDR_WORDS (MH_LANES / 2)        /* chunk header: 64 x u16 sub-stream bit lengths   */
+#define MH_HDR_WORDS (MH_LANES / 2)        /* upper bound of a chunk header (slot sizing); the header
+                                              itself is 1..25 words: 12-bit minimum sub-stream length,
+                                              4-bit field width w, 64 w-bit (length - minimum) fields */
 
 /* mapper: which symbol -> rank permutation the calibration yields */
 #define MH_MODE_NOSORT 0 /* identity          Compressing data/get_BR_no_sort.py:174,192        */

@@ -337,6 +337,20 @@ static inline void put_bits(uint32_t *w, uint64_t pos, uint32_t code_rev, uint32
     if (v >> 32) w[(pos >> 5) + 1] |= (uint32_t)(v >> 32);
 }
 
+/* Chunk header, format revision 2 (build-defined; the reference has no bitstream):
+ *   bits [0,12)  min  = shortest sub-stream length of the chunk (<= 256 * 9 = 2304)
+ *   bits [12,16) w    = bits needed for (longest - shortest), 0..12
+ *   then 64 fields of w bits, field l = length of sub-stream l minus min, LSB-first from bit 16
+ *   header words = ceil((16 + 64 * w) / 32) = 1..25; the payload starts at the next word. */
+static uint32_t hdr_width(uint32_t range)
+{
+    uint32_t w = 0;
+    while (range >> w) ++w;
+    return w;
+}
+
+static uint32_t hdr_words(uint32_t w) { return (16u + 64u * w + 31u) >> 5; }
+
 /* one chunk of m <= MHO_CHUNK samples -> words; returns words written */
 static uint64_t encode_chunk(const uint8_t *x, uint32_t m, const enc_lut *lut, uint32_t *out,
                              uint64_t *bits)
@@ -360,10 +374,18 @@ static uint64_t encode_chunk(const uint8_t *x, uint32_t m, const enc_lut *lut, u
     uint64_t B = 0;
     for (int l = 0; l < MHO_LANES; ++l) B += lane_len[l];
     const uint64_t nw = (B + 31) / 32;
-    memset(out, 0, (MHO_HDR_WORDS + nw) * sizeof(uint32_t));
-    for (int l = 0; l < MHO_LANES; ++l) out[l >> 1] |= lane_len[l] << (16 * (l & 1));
+    uint32_t mn = lane_len[0], mx = lane_len[0];
+    for (int l = 1; l < MHO_LANES; ++l) {
+        if (lane_len[l] < mn) mn = lane_len[l];
+        if (lane_len[l] > mx) mx = lane_len[l];
+    }
+    const uint32_t w = hdr_width(mx - mn), hw = hdr_words(w);
+    memset(out, 0, (hw + nw) * sizeof(uint32_t));
+    out[0] = mn | (w << 12);
+    for (int l = 0; l < MHO_LANES; ++l)
+        if (w) put_bits(out, 16 + (uint64_t)l * w, lane_len[l] - mn, w);
     /* pass 2: emit */
-    uint32_t *pay = out + MHO_HDR_WORDS;
+    uint32_t *pay = out + hw;
     uint64_t pos = 0;
     for (int l = 0; l < MHO_LANES; ++l) {
         for (int k = 0; k < MHO_ROWS; ++k) {
@@ -379,7 +401,7 @@ static uint64_t encode_chunk(const uint8_t *x, uint32_t m, const enc_lut *lut, u
         }
     }
     *bits += B;
-    return MHO_HDR_WORDS + nw;
+    return hw + nw;
 }
 
 uint64_t mho_encode_segment(const uint8_t *x, uint64_t n, const mho_params *p,
@@ -425,9 +447,19 @@ static uint64_t decode_chunk(const uint32_t *in, uint32_t m, const dec_tab *t, u
 {
     uint64_t P[MHO_LANES + 1];
     P[0] = 0;
-    for (int l = 0; l < MHO_LANES; ++l) P[l + 1] = P[l] + ((in[l >> 1] >> (16 * (l & 1))) & 0xFFFFu);
+    const uint32_t mn = in[0] & 0xFFFu, w = (in[0] >> 12) & 15u, hw = hdr_words(w);
+    for (int l = 0; l < MHO_LANES; ++l) {
+        uint32_t f = 0;
+        if (w) {
+            const uint64_t fb = 16 + (uint64_t)l * w;
+            uint64_t v = in[fb >> 5];
+            if ((fb & 31) + w > 32) v |= (uint64_t)in[(fb >> 5) + 1] << 32;
+            f = (uint32_t)(v >> (fb & 31)) & ((1u << w) - 1u);
+        }
+        P[l + 1] = P[l] + mn + f;
+    }
     const uint64_t nw = (P[MHO_LANES] + 31) / 32;
-    const uint32_t *pay = in + MHO_HDR_WORDS;
+    const uint32_t *pay = in + hw;
     const uint32_t mask = (1u << t->maxlen) - 1;
     for (int l = 0; l < MHO_LANES; ++l) {
         uint64_t pos = P[l];
@@ -445,7 +477,7 @@ static uint64_t decode_chunk(const uint32_t *in, uint32_t m, const dec_tab *t, u
             }
         }
     }
-    return MHO_HDR_WORDS + nw;
+    return hw + nw;
 }
 
 uint64_t mho_decode_segment(const uint32_t *in, uint64_t n, const mho_params *p, uint8_t peak,

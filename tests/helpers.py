@@ -57,3 +57,17 @@ def same_float(a, b):
     """bit-exact float64 equality, nan == nan"""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def chunk_header(words):
+    """Independent parser of a chunk header (container format revision 2):
+    words = uint32 array starting at the chunk.  Returns (sub-stream bit lengths [64], header words)."""
+    import numpy as np
+    w0 = int(words[0])
+    mn, w = w0 & 0xFFF, (w0 >> 12) & 15
+    hw = (16 + 64 * w + 31) // 32
+    bits = 0
+    for i in range(hw):                      # the header as one little-endian bit string
+        bits |= int(words[i]) << (32 * i)
+    lens = np.array([mn + ((bits >> (16 + l * w)) & ((1 << w) - 1)) for l in range(64)], dtype=np.int64)
+    return lens, hw

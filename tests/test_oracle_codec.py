@@ -77,10 +77,11 @@ def test_roundtrip_and_bit_totals(S, h, mode, window):
     for s in range(len(seg["ch"])):
         w, left = int(seg["off"][s]), int(seg["n"][s])
         while left > 0:
-            hdr = enc["payload"][w:w + OC.HDR_WORDS].view(np.uint16)
-            B = int(hdr.sum())
+            lens_, hw = helpers.chunk_header(enc["payload"][w:w + OC.HDR_WORDS])
+            assert 1 <= hw <= 25
+            B = int(lens_.sum())
             tot[seg["ch"][s]] += B
-            w += OC.HDR_WORDS + (B + 31) // 32
+            w += hw + (B + 31) // 32
             left -= OC.CHUNK
         assert w - int(seg["off"][s]) == int(enc["seg_words"][s])
     assert np.array_equal(tot, enc["ch_bits"])
