@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from .codec import _ptr, _stream
-from .container import ChannelSet, layout
+from .container import ChannelSet
 
 
 def channel_rates(C, lo=0.2, hi=3.0, first_channel=0):

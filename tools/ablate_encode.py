@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
 """Timing-only ablations of k_encode2 (S=3 kernel): which phase costs what.  Debug tool."""
-import ctypes as ct
 import os
 import sys
 

@@ -7,7 +7,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-import muahuff
 from muahuff import sclv
 from muahuff.stream import StreamEncoder
 

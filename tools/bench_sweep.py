@@ -11,7 +11,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-import muahuff
 from muahuff.drivers import get_BR_with_approx_sort
 
 C, T = int(os.environ.get("C", "192")), int(os.environ.get("T", "20000"))
