@@ -4,7 +4,9 @@
  * smallest complete client of it.  Device memory comes straight from the HIP runtime; the
  * input is generated on the GPU (mh_synth_poisson), then measured, encoded, decoded, and the
  * decoded window is compared on the host with min(x, S-1) -- the clip the reference applies
- * before it histograms a channel (Compressing data/get_BR_with_approx_sort.py:164).
+ * before it histograms a channel (Compressing data/get_BR_with_approx_sort.py:164).  It then
+ * walks the rest of the device entry points: mh_compact + decode from the dense stream,
+ * mh_encode_preset, mh_interleave / mh_deinterleave, mh_rebin.
  *
  * Build (done by __graft_entry__.build()):
  *   gcc -O2 -std=c11 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/abi_roundtrip.c \
@@ -128,13 +130,79 @@ int main(int argc, char **argv)
         bad += chbits[c] != bits[c];
         sum_bits += bits[c];
     }
+    /* ---- dense form: mh_compact, then decode straight from the packed stream ---------------- */
+    uint64_t *d_doff, *d_total, total_words = 0;
+    uint32_t *d_dense;
+    HIP(hipMalloc((void **)&d_doff, (info.n_segments + 1) * 8));
+    HIP(hipMalloc((void **)&d_total, 8));
+    HIP(hipMalloc((void **)&d_dense, info.payload_cap_words * 4));
+    MH(mh_compact(plan, d_pay, d_segw, d_dense, info.payload_cap_words, d_doff, d_total, NULL));
+    HIP(hipMemset(d_out, 0xEE, total + 16));
+    MH(mh_decode(plan, d_dense, d_doff, d_peak, d_enc, d_out, NULL));
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(&total_words, d_total, 8, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(y, d_out, total, hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < C; ++c) {
+        const uint64_t c0 = len[c] < 64 ? len[c] : 64;
+        for (uint64_t t = c0; t < len[c]; ++t)
+            bad += y[off[c] + t] != (x[off[c] + t] < S - 1 ? x[off[c] + t] : S - 1);
+    }
+    bad += total_words * 32 < sum_bits; /* the container holds at least the code bits */
+
+    /* ---- calibrate-then-stream: encode again with the (peak, encoder) words found above ----- */
+    MH(mh_encode_preset(plan, d_data, d_peak, d_enc, d_pay, info.payload_cap_words, d_segw, d_chbits, NULL));
+    HIP(hipDeviceSynchronize());
+    HIP(hipMemcpy(chbits, d_chbits, C * 8, hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < C; ++c) bad += chbits[c] != bits[c];
+
+    /* ---- layout helpers: time-major <-> channel-major, re-binning ---------------------------- */
+    {
+        const uint64_t Tm = 1000;           /* first 1000 bins of every channel as a [Tm][C] block */
+        uint8_t *d_tm, *d_cm, *tm = malloc(Tm * C), *cm = malloc((size_t)C * 1008);
+        uint64_t *coff = malloc(C * 8), *d_coff;
+        for (uint32_t c = 0; c < C; ++c) coff[c] = (uint64_t)c * 1008;
+        HIP(hipMalloc((void **)&d_tm, Tm * C));
+        HIP(hipMalloc((void **)&d_cm, (size_t)C * 1008));
+        HIP(hipMalloc((void **)&d_coff, C * 8));
+        HIP(hipMemcpy(d_coff, coff, C * 8, hipMemcpyHostToDevice));
+        if (T >= Tm + 40) {
+            MH(mh_interleave(d_data, d_off, Tm, C, d_tm, NULL));       /* channel-major -> |CH1|..|CHN| */
+            MH(mh_deinterleave(d_tm, Tm, C, d_cm, d_coff, NULL));       /* and back into a new layout   */
+            HIP(hipDeviceSynchronize());
+            HIP(hipMemcpy(tm, d_tm, Tm * C, hipMemcpyDeviceToHost));
+            HIP(hipMemcpy(cm, d_cm, (size_t)C * 1008, hipMemcpyDeviceToHost));
+            for (uint32_t c = 0; c < C; ++c)
+                for (uint64_t t = 0; t < Tm; ++t) {
+                    bad += tm[t * C + c] != x[off[c] + t];
+                    bad += cm[coff[c] + t] != x[off[c] + t];
+                }
+            /* 5 ms bins from the 1 ms counts, saturating like MATLAB uint8() */
+            uint8_t *d_rb, *rb = malloc((size_t)C * 200);
+            uint64_t *roff = malloc(C * 8), *rlen = malloc(C * 8), *d_roff, *d_rlen;
+            for (uint32_t c = 0; c < C; ++c) { roff[c] = (uint64_t)c * 200; rlen[c] = Tm; }
+            HIP(hipMalloc((void **)&d_rb, (size_t)C * 200));
+            HIP(hipMalloc((void **)&d_roff, C * 8));
+            HIP(hipMalloc((void **)&d_rlen, C * 8));
+            HIP(hipMemcpy(d_roff, roff, C * 8, hipMemcpyHostToDevice));
+            HIP(hipMemcpy(d_rlen, rlen, C * 8, hipMemcpyHostToDevice));
+            MH(mh_rebin(d_cm, d_coff, d_rlen, C, Tm, 5, 1, d_rb, d_roff, NULL));
+            HIP(hipDeviceSynchronize());
+            HIP(hipMemcpy(rb, d_rb, (size_t)C * 200, hipMemcpyDeviceToHost));
+            for (uint32_t c = 0; c < C; ++c)
+                for (uint64_t b = 0; b < 200; ++b) {
+                    unsigned sum = 0;
+                    for (int k = 0; k < 5; ++k) sum += x[off[c] + b * 5 + k];
+                    bad += rb[roff[c] + b] != (sum > 255 ? 255 : sum);
+                }
+        }
+    }
     MH(mh_plan_destroy(plan));
     if (bad) {
         fprintf(stderr, "MISMATCH: %llu differences\n", (unsigned long long)bad);
         return 1;
     }
-    printf("OK %s (%s, %d CUs): %u channels, %llu samples, %.4f bits/sample, decode == clip(x), "
-           "encoded bits == SCLV . histogram\n",
-           name, arch, cus, C, (unsigned long long)info.window_samples, (double)sum_bits / (double)info.window_samples);
+    printf("OK %s (%s, %d CUs): %u channels, %llu samples, %.4f bits/sample, decode == clip(x) (slots and dense), "
+           "encoded bits == SCLV . histogram, preset encode, layout and re-binning helpers agree with the host\n",
+           name, arch, cus, C, (unsigned long long)info.window_samples, info.window_samples ? (double)sum_bits / (double)info.window_samples : 0.0);
     return 0;
 }
