@@ -73,13 +73,17 @@ __global__ __launch_bounds__(256) void k_rebin2(const uint8_t *__restrict__ data
 // and stores its g results as one 4/2/1-byte (uint8 output) or 16/8/4-byte (uint32) access.
 // A workgroup walks `tpw` consecutive tiles of one channel; the next tile's 16-byte loads are
 // issued into registers before the current tile is summed.
-template <bool SAT>
+// RC: the bin factor as a compile-time constant (the reference's periods 5, 10, 20, 50, 100: the
+// walk unrolls into straight-line code with literal masks) or 0 for any r at run time.
+template <bool SAT, int RC>
 __global__ __launch_bounds__(256) void k_rebin3(const uint8_t *__restrict__ data, const uint64_t *in_off,
-                                                const uint64_t *in_len, uint32_t C, uint32_t r, uint32_t g,
-                                                uint32_t u, uint32_t upt, uint32_t tpw, void *__restrict__ out,
+                                                const uint64_t *in_len, uint32_t C, uint32_t r_arg, uint32_t g_arg,
+                                                uint32_t u_arg, uint32_t upt, uint32_t tpw, void *__restrict__ out,
                                                 const uint64_t *out_off)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kRebinTileBytes / 4];
+    constexpr uint32_t kG = RC == 0 ? 0u : RC % 4 == 0 ? 1u : RC % 2 == 0 ? 2u : 4u;
+    const uint32_t r = RC ? (uint32_t)RC : r_arg, g = RC ? kG : g_arg, u = RC ? kG * (uint32_t)RC / 4 : u_arg;
     const uint32_t tile_bytes = upt * u * 4;  // <= kRebinTileBytes
     constexpr int kVec = kRebinTileBytes / 16 / 256;  // 16-byte vectors per thread and tile
     for (uint32_t ch = blockIdx.y; ch < C; ch += gridDim.y) {
@@ -147,14 +151,23 @@ __global__ __launch_bounds__(256) void k_rebin3(const uint8_t *__restrict__ data
                             rem = r;
                         }
                     };
-                    // LDS reads batched 8 ahead of the (wave-uniform) walk so their latency overlaps
-                    for (uint32_t w0 = 0; w0 < u; w0 += 8) {
-                        uint32_t vv[8];
+                    if (RC) {  // compile-time unit: all reads first, then a fully unrolled walk
+                        constexpr uint32_t kU = RC ? kG * (uint32_t)RC / 4 : 1u;
+                        uint32_t vv[kU];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) vv[j] = w0 + j < u ? p[w0 + j] : 0u;
+                        for (uint32_t j = 0; j < kU; ++j) vv[j] = p[j];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (w0 + j < u) step(vv[j]);
+                        for (uint32_t j = 0; j < kU; ++j) step(vv[j]);
+                    } else {
+                        // LDS reads batched 8 ahead of the (wave-uniform) walk so their latency overlaps
+                        for (uint32_t w0 = 0; w0 < u; w0 += 8) {
+                            uint32_t vv[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) vv[j] = w0 + j < u ? p[w0 + j] : 0u;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (w0 + j < u) step(vv[j]);
+                        }
                     }
                     const uint32_t valid = nb - b < g ? (uint32_t)(nb - b) : g;
                     if (SAT) {

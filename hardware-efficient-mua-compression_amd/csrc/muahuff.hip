@@ -719,12 +719,26 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
         uint64_t bx = ((max_len + tile_bytes - 1) / tile_bytes + tpw - 1) / tpw;
         if (bx == 0) bx = 1;
         if (bx > 65535) bx = 65535;
-        if (saturate)
-            hipLaunchKernelGGL(mh::k_rebin3<true>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
-                               data, in_off, in_len, C, r, g, u, upt, tpw, out, out_off);
-        else
-            hipLaunchKernelGGL(mh::k_rebin3<false>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream,
-                               data, in_off, in_len, C, r, g, u, upt, tpw, out, out_off);
+#define MH_REBIN3(SAT_, R_)                                                                              \
+    hipLaunchKernelGGL((mh::k_rebin3<SAT_, R_>), dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, \
+                       data, in_off, in_len, C, r, g, u, upt, tpw, out, out_off)
+#define MH_REBIN3_R(R_)               \
+    do {                              \
+        if (saturate)                 \
+            MH_REBIN3(true, R_);      \
+        else                          \
+            MH_REBIN3(false, R_);     \
+    } while (0)
+        switch (r) {  // the reference's bin periods get straight-line kernels
+        case 5: MH_REBIN3_R(5); break;
+        case 10: MH_REBIN3_R(10); break;
+        case 20: MH_REBIN3_R(20); break;
+        case 50: MH_REBIN3_R(50); break;
+        case 100: MH_REBIN3_R(100); break;
+        default: MH_REBIN3_R(0); break;
+        }
+#undef MH_REBIN3_R
+#undef MH_REBIN3
         MH_HIP(hipGetLastError());
         return MH_OK;
     }
