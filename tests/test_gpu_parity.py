@@ -610,3 +610,27 @@ def test_random_access_decompress_of_selected_channels(mh):
                 assert np.array_equal(g, full[i]), (S, window, i)
         with pytest.raises(IndexError):
             cio.decompress(c, channels=[10])
+
+
+def test_integration_md_ctypes_stub_runs(mh):
+    """The ctypes binding printed in INTEGRATION.md section 4 is executed as written (only the
+    library path is made absolute) and must reproduce the oracle's per-channel figures."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def measure(" in b)
+    block = block.replace('ct.CDLL("hardware-efficient-mua-compression_amd/libmuahuff.so")',
+                          'ct.CDLL(%r)' % os.path.join(root, "hardware-efficient-mua-compression_amd", "libmuahuff.so"))
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.RandomState(31)
+    chans = _channels(rng, [5000, 70001, 333, 16384, 40000])
+    tab = helpers.sclv_tables()[5]
+    cal, post, bits, skip, n = ns["measure"](chans, 5, 6, True, tab)
+    data, off, ln = OC.flatten(chans)
+    om = OC.measure(data, off, ln, OC.Params(5, 6, 1, OC.WIN_REF_HALF, tab))
+    assert np.array_equal(bits.astype(np.uint64), om["bits"])
+    assert np.array_equal(post.astype(np.uint64), om["post_mapped"])
+    assert np.array_equal(skip, om["skipped"])
+    assert np.array_equal(n, om["post_mapped"].sum(1).astype(np.float64))
