@@ -25,7 +25,10 @@ def timed(f, n=20):
 
 for name, C, T, lo, hi in (("96 ch x 3.6e6 bins (1 ms bins, 1 h)", 96, 3_600_000, 0.005, 0.08),
                            ("96 ch x 72 000 bins (50 ms bins, 1 h)", 96, 72_000, 0.2, 3.0),
-                           ("1344 ch x 72 000 bins (test set B stand-in, 50 ms)", 1344, 72_000, 0.2, 3.0)):
+                           ("1344 ch x 72 000 bins (test set B stand-in, 50 ms)", 1344, 72_000, 0.2, 3.0),
+                           ("2400 ch x 72 000 bins (training set stand-in, 50 ms)", 2400, 72_000, 0.2, 3.0),
+                           ("10 000 ch x 20 000 bins (many short channels)", 10_000, 20_000, 0.2, 3.0),
+                           ("2400 ch x 360 000 bins (10 ms bins)", 2400, 360_000, 0.05, 0.8)):
     cs = synth.generate(C, T, seed=5, lo=lo, hi=hi)
     plan = codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(3))
     enc = plan.alloc_encoded()
