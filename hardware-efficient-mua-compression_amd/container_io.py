@@ -133,33 +133,106 @@ def compress(cs, S, h, mode, sclv, window=None, seg_chunks=2):
 def segments_per_channel(ch_len, h, window, seg_chunks):
     """Number of directory entries of each channel: the window rule of include/muahuff.h applied
     to the channel length, cut into segments of seg_chunks chunks (the planner's layout)."""
-    from . import CHUNK, WIN_AFTER_CAL, WIN_FULL, WIN_REF_HALF, WIN_REF_HALF_TRUNC
+    from . import CHUNK
+    seg = int(seg_chunks) * CHUNK
+    return (window_lengths(ch_len, h, window) + seg - 1) // seg
+
+
+def window_lengths(ch_len, h, window):
+    """Samples in the encoded window of each channel (the rules of include/muahuff.h)."""
+    from . import WIN_AFTER_CAL, WIN_FULL, WIN_REF_HALF, WIN_REF_HALF_TRUNC
     T = np.asarray(ch_len, dtype=np.int64)
     c = np.minimum(np.int64(1) << int(h), T)
     e = c + T // 2
     if window == WIN_REF_HALF:
-        n = np.where(e > T, 0, e - c)
-    elif window == WIN_REF_HALF_TRUNC:
-        n = np.minimum(e, T) - c
-    elif window == WIN_AFTER_CAL:
-        n = T - c
-    elif window == WIN_FULL:
-        n = T
-    else:
-        raise ValueError("unknown window rule %r" % (window,))
-    seg = int(seg_chunks) * CHUNK
-    return (n + seg - 1) // seg
+        return np.where(e > T, 0, e - c)
+    if window == WIN_REF_HALF_TRUNC:
+        return np.minimum(e, T) - c
+    if window == WIN_AFTER_CAL:
+        return T - c
+    if window == WIN_FULL:
+        return T
+    raise ValueError("unknown window rule %r" % (window,))
 
 
-def decompress(c, device="cuda", channels=None):
+def validate(c):
+    """Structural check of a container before it goes to the GPU (mh_decode trusts its input: a
+    corrupt chunk header would send the kernel's reads outside the payload).  Walks the chunk
+    headers of every segment on the host -- vectorised over segments -- and verifies that the
+    chunk sizes they imply add up exactly to the directory's word counts, that lengths are
+    possible for the code (<= 256 * max code length) and that per-channel metadata is in range.
+    Raises ValueError."""
+    from . import CHUNK
+    hd = c.header
+    S, K = int(hd["S"]), int(hd["K"])
+    sclv = np.array(hd["sclv"], np.int64).reshape(K, S)
+    if not (2 <= S <= 10) or sclv.min() < 1 or sclv.max() > 9:
+        raise ValueError("container header: S / code lengths out of range")
+    C = len(c.ch_len)
+    if not (len(c.peak) == len(c.enc) == len(c.skipped) == len(c.ch_bits) == C):
+        raise ValueError("container arrays disagree about the channel count")
+    if C and (int(c.enc.max()) >= K or int(c.peak.max()) >= S):
+        raise ValueError("per-channel (peak, encoder) word out of range")
+    n_win = window_lengths(c.ch_len, hd["h"], hd["window"])
+    seg = int(hd["seg_chunks"]) * CHUNK
+    nseg_ch = (n_win + seg - 1) // seg
+    nseg = int(nseg_ch.sum())
+    if nseg != len(c.seg_words):
+        raise ValueError("container directory does not match its header")
+    if int(c.seg_words.sum()) != c.payload.size:
+        raise ValueError("payload size does not match the directory")
+    if nseg == 0:
+        return
+    seg_ch = np.repeat(np.arange(C), nseg_ch)
+    first = np.concatenate([[0], np.cumsum(nseg_ch)])[:-1]
+    k_in_ch = np.arange(nseg) - np.repeat(first, nseg_ch)               # segment index inside its channel
+    seg_n = np.minimum(n_win[seg_ch] - k_in_ch * seg, seg)             # samples per segment
+    maxlen = sclv[c.enc[seg_ch].astype(np.int64)].max(axis=1)          # longest code of the channel's encoder
+    start = np.concatenate([[0], np.cumsum(c.seg_words.astype(np.int64))])
+    pos, end = start[:-1].copy(), start[1:]
+    pay = np.concatenate([c.payload, np.zeros(32, np.uint32)]).astype(np.uint64)
+    lanes = np.arange(64, dtype=np.int64)
+    left = seg_n.copy()
+    for _ in range(int(hd["seg_chunks"])):
+        act = np.nonzero(left > 0)[0]
+        if act.size == 0:
+            break
+        p = pos[act]
+        if np.any(p >= end[act]):
+            raise ValueError("segment shorter than its chunk headers say")
+        w0 = pay[p]
+        mn, w = (w0 & 0xFFF).astype(np.int64), ((w0 >> 12) & 15).astype(np.int64)
+        if np.any(w > 12):
+            raise ValueError("chunk header: field width above 12")
+        hw = (16 + 64 * w + 31) >> 5
+        fb = 16 + lanes[None, :] * w[:, None]                           # [segments, 64] field bit positions
+        wi = p[:, None] + (fb >> 5)
+        v = pay[wi] | (pay[wi + 1] << np.uint64(32))
+        f = ((v >> (fb & 31).astype(np.uint64)) & ((np.uint64(1) << w[:, None].astype(np.uint64)) - np.uint64(1))).astype(np.int64)
+        lens = mn[:, None] + f
+        m = np.minimum(left[act], CHUNK)
+        if np.any(lens.max(axis=1) > 256 * maxlen[act]) or np.any(lens.sum(axis=1) > m * maxlen[act]):
+            raise ValueError("chunk header: sub-stream lengths impossible for this code")
+        if np.any(lens.sum(axis=1) < m):                                # every codeword has >= 1 bit
+            raise ValueError("chunk header: fewer bits than samples")
+        pos[act] = p + hw + ((lens.sum(axis=1) + 31) >> 5)
+        left[act] -= m
+    if np.any(left > 0) or np.any(pos != end):
+        raise ValueError("chunk sizes do not add up to the directory's segment sizes")
+
+
+def decompress(c, device="cuda", channels=None, check=True):
     """Inverse of compress(): a ChannelSet whose windows hold min(x, S-1) (bytes outside the
     encoded windows are zero).  channels: optional list of channel indices -- only their segments
     are uploaded and decoded (the directory gives random access per channel); the returned set
-    holds them in the order given."""
+    holds them in the order given.  check=True runs validate() first (containers from disk are
+    untrusted input for a kernel that follows their headers)."""
     import torch
 
     from . import codec
     from .container import ChannelSet
+    if check:
+        validate(c)
     hd = c.header
     nseg_ch = segments_per_channel(c.ch_len, hd["h"], hd["window"], hd["seg_chunks"])
     if int(nseg_ch.sum()) != len(c.seg_words):

@@ -149,7 +149,10 @@ int mh_encode_preset(mh_plan *plan, const uint8_t *data, const uint8_t *peak, co
 /* Inverse of mh_encode: writes clip(x) = min(x, S-1) for every window sample into `out`
  * (same channel layout as the plan's data buffer; bytes outside the windows are left
  * untouched).  seg_off (device, words) = where each segment starts in `payload`; NULL means
- * the plan's slot offsets.  payload must stay readable 4 words past the last segment. */
+ * the plan's slot offsets.  payload must stay readable 4 words past the last segment.
+ * The kernel follows the chunk headers it finds: hand it streams this library produced, and
+ * check streams from storage first (hardware-efficient-mua-compression_amd/container_io.py:
+ * validate() walks every chunk header on the host and rejects anything inconsistent). */
 int mh_decode(mh_plan *plan, const uint32_t *payload, const uint64_t *seg_off,
               const uint8_t *peak, const uint8_t *enc, uint8_t *out, void *stream);
 

@@ -634,3 +634,17 @@ def test_integration_md_ctypes_stub_runs(mh):
     assert np.array_equal(post.astype(np.uint64), om["post_mapped"])
     assert np.array_equal(skip, om["skipped"])
     assert np.array_equal(n, om["post_mapped"].sum(1).astype(np.float64))
+
+
+def test_corrupt_container_is_rejected_before_any_kernel_runs(mh):
+    from muahuff import container_io as cio
+    rng = np.random.RandomState(5)
+    cs = _cs(mh, _channels(rng, [70000, 40000, 100]))
+    c = cio.compress(cs, 3, 6, 1, helpers.sclv_tables()[3])
+    cio.validate(c)
+    bad = cio.Compressed(c.header, c.ch_len, c.peak, c.enc, c.skipped, c.ch_bits, c.seg_words, c.payload.copy())
+    bad.payload[0] ^= 0x3000  # field width of the first chunk
+    with pytest.raises(ValueError):
+        cio.decompress(bad)
+    good = cio.decompress(c).to_channels()
+    assert np.array_equal(good[0][64:], np.minimum(cs.to_channels()[0][64:], 2))

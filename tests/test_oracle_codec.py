@@ -119,3 +119,56 @@ def test_rebin():
             want = pad.reshape(nb, r).sum(1)
             assert np.array_equal(OC.rebin_u32(x, r), want)
             assert np.array_equal(OC.rebin_u8(x, r), np.minimum(want, 255))
+
+
+def _oracle_container(chans, S, h, mode, window, tab, seg_chunks=2):
+    from muahuff import container_io as cio
+    data, off, ln = OC.flatten(chans)
+    e = OC.encode(data, off, ln, OC.Params(S, h, mode, window, tab, seg_chunks=seg_chunks))
+    seg = e["seg"]
+    parts = [e["payload"][int(o):int(o) + int(n)] for o, n in zip(seg["off"], e["seg_words"])]
+    dense = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+    return cio.Compressed(cio.make_header(S, h, mode, window, seg_chunks, tab), ln.copy(), e["peak"], e["enc"],
+                          e["skipped"], e["ch_bits"], e["seg_words"].astype(np.uint64), dense)
+
+
+def test_container_validation_accepts_good_and_rejects_corrupt_streams():
+    """container_io.validate (the host-side gate in front of mh_decode) on containers built by the
+    oracle: every window rule passes; header corruption, truncation, directory or metadata damage
+    is reported as ValueError instead of reaching the GPU."""
+    import dataclasses
+
+    from muahuff import container_io as cio
+    rng = np.random.RandomState(3)
+    lens = [5, 70000, 33, 16384 + 64, 100, 40001, 64, 65, 200000, 3]
+    chans = [np.minimum(rng.poisson(r, size=T), 255).astype(np.uint8)
+             for T, r in zip(lens, [0.1, 0.5, 1.0, 2.0, 3.0, 0.3, 1.5, 0.7, 0.05, 4.0])]
+    tabs = helpers.sclv_tables()
+    for S, h, mode, window, sc in ((3, 6, 1, 0, 2), (5, 6, 1, 2, 1), (10, 3, 0, 1, 4), (4, 8, 1, 3, 2), (2, 2, 0, 2, 3)):
+        c = _oracle_container(chans, S, h, mode, window, tabs[S], sc)
+        cio.validate(c)
+        assert np.array_equal(cio.segments_per_channel(c.ch_len, h, window, sc).sum(), len(c.seg_words))
+        if c.payload.size == 0:
+            continue
+        rep = lambda **kw: dataclasses.replace(c, **kw)
+        flipped = 0
+        for trial in range(40):  # single-bit flips in the first header word of random segments
+            p = c.payload.copy()
+            starts = np.concatenate([[0], np.cumsum(c.seg_words.astype(np.int64))])[:-1]
+            w = int(starts[rng.randint(len(starts))])
+            p[w] ^= np.uint32(1 << int(rng.randint(0, 16)))
+            try:
+                cio.validate(rep(payload=p))
+            except ValueError:
+                flipped += 1
+        assert flipped == 40  # min / width bits always change the implied chunk size
+        with pytest.raises(ValueError):
+            cio.validate(rep(payload=c.payload[:-1]))
+        with pytest.raises(ValueError):
+            sw = c.seg_words.copy()
+            sw[0] += 1
+            cio.validate(rep(seg_words=sw))
+        with pytest.raises(ValueError):
+            cio.validate(rep(enc=np.full_like(c.enc, 200)))
+        with pytest.raises(ValueError):
+            cio.validate(rep(ch_len=c.ch_len[:-1]))
