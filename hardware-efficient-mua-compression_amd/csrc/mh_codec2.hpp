@@ -93,9 +93,10 @@ __device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src,
     return make_uint2(hw + nw, B);
 }
 
-// LC: 0 maxlen<=2 (flush check per piece), 1 maxlen<=4 (per 2 dwords), 2 maxlen<=8 (per dword),
-//     3 maxlen==9 (as 2, with a wave-uniform escape to per-pair flushing when four codewords
-//       exceed 32 bits)
+// LC: accumulator checks.  0 maxlen<=2: one per piece; 1 maxlen<=4: one per 2 dwords (8 codewords
+//     always fit 32 bits); 2 maxlen<=8: one per 2 dwords when 8 codewords fit 32 bits in every lane
+//     of the wave, else one per dword; 3 maxlen==9: as 2, plus a per-pair route when four codewords
+//     exceed a dword.  The escapes are wave-uniform branches on __any().
 // PB: bits per symbol in the pair index.  PB=3 (S<=8) keeps the hot entries (small symbols) on
 //     distinct LDS banks; PB=4 (S=9,10) xor-swizzles the index for the same reason.
 constexpr int kWin = 8;  // rows (1 KiB each) a wave keeps in flight
@@ -271,25 +272,40 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
             x.z = clip_word<PB>(x.z);
             x.w = clip_word<PB>(x.w);
         }
+        if (LC >= 2) {
+            // long codes: two dwords (8 codewords) share one accumulator check whenever they fit 32 bits
+            // in every lane of the wave; otherwise dword by dword, and for 9-bit codes pair by pair
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const uint32_t y = pair_index_word<PB>(x[d]);
-            const uint2 e0 = lut2[y & 0xFFu];
-            const uint2 e1 = lut2[(y >> 16) & 0xFFu];
-            if (LC == 3 && __builtin_expect(__any(e0.y + e1.y > 32u), 0)) {
-                // four codewords longer than a dword somewhere in the wave (needs four symbols
-                // of rank >= 7 in a row): pair by pair
-                acc |= (uint64_t)e0.x << nb;
-                nb += e0.y;
-                MH_FLUSH();
-                acc |= (uint64_t)e1.x << nb;
-                nb += e1.y;
-                MH_FLUSH();
-            } else {
+            for (int dp = 0; dp < 2; ++dp) {
+                const uint32_t y0 = pair_index_word<PB>(x[2 * dp]), y1 = pair_index_word<PB>(x[2 * dp + 1]);
+                const uint2 a0 = lut2[y0 & 0xFFu], a1 = lut2[(y0 >> 16) & 0xFFu];
+                const uint2 b0 = lut2[y1 & 0xFFu], b1 = lut2[(y1 >> 16) & 0xFFu];
+                const uint32_t t0 = a0.y + a1.y, t1 = b0.y + b1.y;
+                if (LC == 3 && __builtin_expect(__any(t0 > 32u || t1 > 32u), 0)) {
+                    acc |= (uint64_t)a0.x << nb; nb += a0.y; MH_FLUSH();
+                    acc |= (uint64_t)a1.x << nb; nb += a1.y; MH_FLUSH();
+                    acc |= (uint64_t)b0.x << nb; nb += b0.y; MH_FLUSH();
+                    acc |= (uint64_t)b1.x << nb; nb += b1.y; MH_FLUSH();
+                } else if (__any(t0 + t1 > 32u)) {
+                    acc |= (uint64_t)(a0.x | (a1.x << a0.y)) << nb; nb += t0; MH_FLUSH();
+                    acc |= (uint64_t)(b0.x | (b1.x << b0.y)) << nb; nb += t1; MH_FLUSH();
+                } else {
+                    const uint32_t q0 = a0.x | (a1.x << a0.y), q1 = b0.x | (b1.x << b0.y);
+                    acc |= (uint64_t)(q0 | (q1 << t0)) << nb;
+                    nb += t0 + t1;
+                    MH_FLUSH();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t y = pair_index_word<PB>(x[d]);
+                const uint2 e0 = lut2[y & 0xFFu];
+                const uint2 e1 = lut2[(y >> 16) & 0xFFu];
                 const uint32_t q = e0.x | (e1.x << e0.y);
                 acc |= (uint64_t)q << nb;
                 nb += e0.y + e1.y;
-                if (LC >= 2 || (LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
+                if ((LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
             }
         }
     }
