@@ -143,13 +143,15 @@ class Plan:
                                         _ptr(enc.enc), _ptr(out), _stream()))
         return out
 
-    def compact(self, enc, dense=None):
-        """Pack the used words of all segments back to back (for storage / the RCCL gather)."""
+    def compact(self, enc, dense=None, off=None, tot=None):
+        """Pack the used words of all segments back to back (for storage / the RCCL gather).
+        dense / off / tot: optional preallocated outputs (int32 words, int64 [n_segments], int64 [1]);
+        with all three given the call enqueues kernels only."""
         if dense is None:
             total = int(enc.seg_words.sum().item())
             dense = torch.empty(total + 4, dtype=torch.int32, device=self.device)
-        off = self._z(max(self.n_segments, 1), torch.int64)
-        tot = self._z(1, torch.int64)
+        off = self._z(max(self.n_segments, 1), torch.int64) if off is None else off
+        tot = self._z(1, torch.int64) if tot is None else tot
         _lib.check(_lib.lib().mh_compact(self._h, _ptr(enc.payload), _ptr(enc.seg_words), _ptr(dense),
                                          dense.numel(), _ptr(off), _ptr(tot), _stream()))
         return Encoded(dense, enc.seg_words, enc.ch_bits, enc.peak, enc.enc, enc.skipped, off, True), tot

@@ -424,6 +424,34 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint64_t *seg_words, u
     }
 }
 
+// <= kScanBlock segments (small recordings, stream blocks): the whole scan in one workgroup and
+// one launch -- these calls are bound by the number of dependent launches, not by bytes
+__global__ __launch_bounds__(256) void k_scan_small(const uint64_t *seg_words, uint64_t nseg, uint64_t *dense_off,
+                                                    uint64_t *total)
+{
+    __shared__ uint64_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t run = 0;
+    for (int j = 0; j < 8; ++j) {
+        const uint64_t i = (uint64_t)j * 256 + threadIdx.x;
+        const uint64_t v = i < nseg ? seg_words[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < nseg) dense_off[i] = run + before + incl - v;
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (threadIdx.x == 0) total[0] = run;
+}
+
 // One wave per segment, kCompactSegs segments per workgroup (a segment is only a few KiB: one
 // workgroup per segment is dispatch-bound).  The destination is word-aligned only, so up to 3
 // head words are peeled off to make the 16-byte stores aligned; the loads take the misalignment.

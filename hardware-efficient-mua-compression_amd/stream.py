@@ -34,6 +34,7 @@ class StreamEncoder:
         torch.cuda.synchronize()
         self.peak, self.enc = m.peak.clone(), m.enc.clone()
         plan.close()
+        self.close()  # cached block plans point at the previous RAM word
         return self.peak, self.enc
 
     def _slot(self, Tb):
@@ -45,9 +46,14 @@ class StreamEncoder:
             cs = ChannelSet.empty([Tb] * self.C, device=self.device)
             plan = codec.Plan(cs.ch_off, cs.ch_len, self.S, 0, self.mode, WIN_FULL, self.sclv,
                               seg_chunks=self.seg_chunks)
-            slot = dict(cs=cs, plan=plan, enc=plan.alloc_encoded(),
+            e = plan.alloc_encoded()
+            # the block's Encoded record points at the stored RAM word: nothing to copy per block
+            e = codec.Encoded(e.payload, e.seg_words, e.ch_bits, self.peak, self.enc, e.skipped, e.seg_off, e.dense)
+            slot = dict(cs=cs, plan=plan, enc=e,
                         d_off=torch.from_numpy(cs.ch_off.astype(np.int64)).to(self.device),
-                        dense=torch.empty(plan.payload_cap_words, dtype=torch.int32, device=self.device))
+                        dense=torch.empty(plan.payload_cap_words, dtype=torch.int32, device=self.device),
+                        off=torch.zeros(max(plan.n_segments, 1), dtype=torch.int64, device=self.device),
+                        tot=torch.zeros(1, dtype=torch.int64, device=self.device))
             self._slots[Tb] = slot
         return slot
 
@@ -71,8 +77,13 @@ class StreamEncoder:
         _lib.check(_lib.lib().mh_deinterleave(ct.c_void_p(t.data_ptr()), Tb, C, ct.c_void_p(cs.data.data_ptr()),
                                               ct.c_void_p(slot["d_off"].data_ptr()),
                                               ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        enc = plan.encode(cs.data, out=slot["enc"], preset=(self.peak, self.enc))
-        dense, tot = plan.compact(enc, dense=slot["dense"])
+        enc = slot["enc"]
+        _lib.check(_lib.lib().mh_encode_preset(plan._h, ct.c_void_p(cs.data.data_ptr()), ct.c_void_p(self.peak.data_ptr()),
+                                               ct.c_void_p(self.enc.data_ptr()), ct.c_void_p(enc.payload.data_ptr()),
+                                               enc.payload.numel(), ct.c_void_p(enc.seg_words.data_ptr()),
+                                               ct.c_void_p(enc.ch_bits.data_ptr()),
+                                               ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        dense, tot = plan.compact(enc, dense=slot["dense"], off=slot["off"], tot=slot["tot"])
         return dense, tot, slot
 
     def encode_block(self, block):
