@@ -34,6 +34,9 @@ struct CalArgs {
     unsigned long long *zero_bits;  // [C] per-channel bit totals to clear
     const uint8_t *skip_src;        // plan's skip flags ...
     uint8_t *skip_dst;              // ... copied to the caller's array
+    // calibration windows longer than a few KiB are histogrammed by the tiled window-histogram
+    // kernel first ([C][16] counts by clipped symbol); NULL = scan the window here
+    const unsigned long long *pre_hist;
 };
 
 __global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
@@ -49,11 +52,26 @@ __global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
     uint32_t cnt[MH_LUT_SYMS];
 #pragma unroll
     for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = 0;
-    for (uint64_t i = lane; i < c; i += 64) {
-        int v = x[i];
-        v = v > S - 1 ? S - 1 : v;  // clip, get_BR_with_approx_sort.py:164
+    if (a.pre_hist) {
+        if (lane == 0) {  // bins 0..S-2 were counted, the top bin is the window length minus the rest
+            uint32_t rest = 0;
 #pragma unroll
-        for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] += (v == s);
+            for (int s = 0; s < MH_LUT_SYMS; ++s)
+                if (s < S - 1) {
+                    cnt[s] = (uint32_t)a.pre_hist[(size_t)ch * kHistStride + s];
+                    rest += cnt[s];
+                }
+#pragma unroll
+            for (int s = 0; s < MH_LUT_SYMS; ++s)
+                if (s == S - 1) cnt[s] = (uint32_t)c - rest;
+        }
+    } else {
+        for (uint64_t i = lane; i < c; i += 64) {
+            int v = x[i];
+            v = v > S - 1 ? S - 1 : v;  // clip, get_BR_with_approx_sort.py:164
+#pragma unroll
+            for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] += (v == s);
+        }
     }
 #pragma unroll
     for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = wave_sum_u32(cnt[s]);

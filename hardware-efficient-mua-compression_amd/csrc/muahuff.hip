@@ -58,6 +58,7 @@ int check_row(const uint8_t *row, int S, uint32_t *maxlen)
 }
 
 constexpr uint32_t kHistTile = 256 * 16 * 32;  // bytes of one histogram tile (128 KiB)
+constexpr uint64_t kCalDirect = 4096;          // longest calibration window k_calibrate scans itself
 
 template <typename T>
 int upload(T **dst, const std::vector<T> &src)
@@ -104,6 +105,11 @@ struct mh_plan {
     uint32_t dec_K = 4;  // symbols per decode-table lookup
     uint32_t dec_NR = 32; // staging registers per lane of the hybrid decoder
     uint64_t *d_scan = nullptr;  // block sums of mh_compact's segment scan
+    // calibration windows above kCalDirect samples: tiles for the window-histogram kernel
+    uint32_t *d_cal_tile_ch = nullptr, *d_cal_tile_n = nullptr;
+    uint64_t *d_cal_tile_start = nullptr;
+    unsigned long long *d_calhist = nullptr;
+    uint64_t n_cal_tiles = 0;
     uint2 *d_dtab2 = nullptr;  // 4-symbol decode tables (dec_K == 4 plans only)
 };
 
@@ -150,6 +156,20 @@ static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, u
     a.peak = peak;
     a.enc = enc;
     a.lut = p->d_lut;
+    a.pre_hist = nullptr;
+    if (p->n_cal_tiles) {  // long calibration windows (2^h > kCalDirect): tiled histogram first
+        MH_HIP(hipMemsetAsync(p->d_calhist, 0, (size_t)a.C * mh::kHistStride * sizeof(unsigned long long), st));
+        mh::HistArgs ha;
+        ha.data = data;
+        ha.ch_off = p->d_ch_off;
+        ha.tile_ch = p->d_cal_tile_ch;
+        ha.tile_start = p->d_cal_tile_start;
+        ha.tile_n = p->d_cal_tile_n;
+        ha.hist = p->d_calhist;
+        ha.tile_slot = nullptr;
+        hipLaunchKernelGGL(mh::k_hist2<4>, dim3((unsigned)p->n_cal_tiles), dim3(256), 0, st, ha, p->info.S);
+        a.pre_hist = p->d_calhist;
+    }
     hipLaunchKernelGGL(mh::k_calibrate, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
     MH_HIP(hipGetLastError());
     return MH_OK;
@@ -318,7 +338,8 @@ int mh_plan_destroy(mh_plan *p)
     void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
-                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_dtab2, p->d_scan};
+                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_dtab2, p->d_scan,
+                    p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -389,6 +410,20 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
             tile_n.push_back((uint32_t)(n - first < kHistTile ? n - first : kHistTile));
         }
     }
+    // calibration: one wave per channel reads the window directly up to kCalDirect samples (the
+    // reference's range is 2^2..2^10); longer windows go through the tiled histogram kernel
+    std::vector<uint32_t> cal_tile_ch, cal_tile_n;
+    std::vector<uint64_t> cal_tile_start;
+    if (lim > kCalDirect)
+        for (uint32_t c = 0; c < C; ++c) {
+            const uint64_t n = len[c] < lim ? len[c] : lim;
+            for (uint64_t first = 0; first < n; first += kHistTile) {
+                cal_tile_ch.push_back(c);
+                cal_tile_start.push_back(first);
+                cal_tile_n.push_back((uint32_t)(n - first < kHistTile ? n - first : kHistTile));
+            }
+        }
+    p->n_cal_tiles = cal_tile_ch.size();
     p->info.n_segments = p->seg_ch.size();
     p->info.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
     p->n_tiles = tile_ch.size();
@@ -431,7 +466,10 @@ static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len
         (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
         (rc = upload(&p->d_task_seg0, task_seg0)) || (rc = upload(&p->d_task_n, task_n)) ||
         (p->dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << p->W))) ||
-        (rc = alloc(&p->d_scan, p->seg_ch.size() / mh::kScanBlock + 2)))
+        (rc = alloc(&p->d_scan, p->seg_ch.size() / mh::kScanBlock + 2)) ||
+        (p->n_cal_tiles && ((rc = upload(&p->d_cal_tile_ch, cal_tile_ch)) || (rc = upload(&p->d_cal_tile_n, cal_tile_n)) ||
+                            (rc = upload(&p->d_cal_tile_start, cal_tile_start)) ||
+                            (rc = alloc(&p->d_calhist, (size_t)C * mh::kHistStride)))))
         return rc;
     return MH_OK;
 }

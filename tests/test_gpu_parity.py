@@ -648,3 +648,28 @@ def test_corrupt_container_is_rejected_before_any_kernel_runs(mh):
         cio.decompress(bad)
     good = cio.decompress(c).to_channels()
     assert np.array_equal(good[0][64:], np.minimum(cs.to_channels()[0][64:], 2))
+
+
+@pytest.mark.parametrize("S,h,mode", [(3, 13, 1), (5, 15, 1), (10, 17, 0), (2, 20, 1)])
+def test_long_calibration_windows(mh, S, h, mode):
+    """2^h above the direct-scan limit: the calibration histogram comes from the tiled histogram
+    kernel; peak / encoder / bits / stream still byte-exact against the oracle."""
+    rng = np.random.RandomState(h)
+    lens = [300001, 5000, 2 ** h, 2 ** h + 1, 2 ** h - 1, 131072 + 5, 1]
+    chans = _channels(rng, lens)
+    cs = _cs(mh, chans)
+    tab = helpers.sclv_tables()[S]
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, mode, mh.WIN_REF_HALF_TRUNC, tab)
+    p = OC.Params(S, h, mode, OC.WIN_REF_HALF_TRUNC, tab)
+    host = cs.data.cpu().numpy()
+    m, om = plan.measure(cs.data), OC.measure(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+    assert np.array_equal(m.peak.cpu().numpy(), om["peak"]) and np.array_equal(m.enc.cpu().numpy(), om["enc"])
+    assert np.array_equal(m.cal_hist.cpu().numpy().astype(np.uint32), om["cal_sorted"])
+    assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), om["bits"])
+    e, oe = plan.encode(cs.data), OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+    assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+    out = torch.zeros_like(cs.data)
+    plan.decode(e, out)
+    want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host), nthreads=8)
+    assert np.array_equal(out.cpu().numpy(), want)
+    plan.close()
