@@ -699,7 +699,10 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
         uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-            if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];  // reads <= 3 words of slack
+            if ((uint32_t)(j * 64) < ns) {  // wave-uniform; the index clamp keeps the last row inside nw + 2
+                const uint32_t i_ = (uint32_t)(j * 64 + lane);
+                R[j] = pay[i_ < ns ? i_ : ns - 1];
+            }
         uint32_t hw_next = 0;
         if (nfull > 1) hw_next = pay[cur.nw + (lane & 31)];
         for (uint32_t c = 0; c < nfull; ++c) {
@@ -718,7 +721,10 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
                 ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
 #pragma unroll
                 for (int j = 0; j < NR; ++j)
-                    if ((uint32_t)(j * 64) < ns) R[j] = pay[j * 64 + lane];
+                    if ((uint32_t)(j * 64) < ns) {
+                        const uint32_t i_ = (uint32_t)(j * 64 + lane);
+                        R[j] = pay[i_ < ns ? i_ : ns - 1];
+                    }
                 if (c + 2 < nfull) hw_next = pay[cur.nw + (lane & 31)];
             }
             if (staged)
