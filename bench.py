@@ -287,7 +287,10 @@ def main():
                                    % (C, T, S, h, tab.shape[0], "approx-sort" if a.mode else "no-sort"),
                        "channels_per_gpu": C, "bins": T, "S": S, "hist_bits": h, "K": int(tab.shape[0]),
                        "seg_chunks": a.seg_chunks, "parallelism": "channels sharded x%d, no data-path collective" % world},
-            "bits_per_sample": {"payload": b, "container": cb},
+            "bits_per_sample": {"payload": b, "container": cb,
+                                # the reference's figure of merit for the same bits (get_BR_with_approx_sort.py:289-292)
+                                # if these were 50 ms bins: BR = 1000 / (BP / bits_per_sample)
+                                "BR_bits_per_s_per_channel_at_BP50": float(codec.bit_rate(bits, samples, 50))},
             "kernels_ms": {"encode_op": enc_ms, "decode_op": dec_ms,
                            "encode_MSamples_s": samples / enc_ms / 1e3, "decode_MSamples_s": samples / dec_ms / 1e3,
                            "measure_op": meas_ms, "measure_MSamples_s": meas_samples / meas_ms / 1e3,
