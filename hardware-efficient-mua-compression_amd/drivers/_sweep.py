@@ -128,15 +128,18 @@ def evaluate(dev, train_idx, val_idx, S, table, BP, approx, python_floats=False)
     for c in range(n_train):
         histograms[:, c] = np.flip(np.sort(tr[c]))
     # validation histograms per histogram size (:157-210)
-    cal_mem, post_mem = [], []
-    c_all = np.zeros((n_val, len(HIST_BITS)))
-    e_all = np.zeros((n_val, len(HIST_BITS)))
+    nh = len(HIST_BITS)
+    cal_all = np.zeros((nh, n_val, S))   # [hist size, channel, rank]
+    post_all = np.zeros((nh, n_val, S))  # zeros for skipped channels
+    c_all = np.zeros((n_val, nh))
+    e_all = np.zeros((n_val, nh))
     for hi, h in enumerate(HIST_BITS):
         v = dev.validation(val_idx, S, h, approx, table)
         c_all[:, hi] = v["cutoff"]
         e_all[:, hi] = v["cutoff"] + (v["length"] // 2)  # :180 int(len/2)
-        cal_mem.append(np.ascontiguousarray(v["cal"].T))    # [S, n_val]
-        post_mem.append(np.ascontiguousarray(v["post"].T))  # zeros for skipped channels
+        cal_all[hi] = v["cal"]
+        post_all[hi] = v["post"]
+    n_all = post_all.sum(axis=2)         # [hist size, channel]
     with np.errstate(invalid="ignore", divide="ignore"):
         proportion = (e_all.astype(int) - c_all.astype(int)) / e_all.astype(int)  # :214
     stored_SCLVs, stored_BRs, stored_hist = [], [], []
@@ -146,22 +149,29 @@ def evaluate(dev, train_idx, val_idx, S, table, BP, approx, python_floats=False)
         dot = histograms.T @ cur.T  # :231 (integer-valued, exact)
         assign = np.argmin(dot, axis=1) if n_train else np.zeros(0, dtype=np.int64)  # :236
         stored_hist.append(np.bincount(assign, minlength=len(cur)).astype(np.int64))  # :239-242
-        per_hist = []
-        for hi in range(len(HIST_BITS)):  # :250-296
-            vdot = cal_mem[hi].T @ cur.T
-            post = post_mem[hi]
-            k = np.argmin(vdot, axis=1) if n_val else np.zeros(0, dtype=np.int64)  # :281 first min
-            # :284-292 for all channels at once: the sums are sums of integer-valued doubles
-            # (exact in any order), the two divisions are element-wise float64 as in the reference
-            n = post.sum(axis=0)
-            bits = (cur[k, :] * post.T).sum(axis=1)
-            br = bit_rate(bits, n, BP)
-            per_hist.append(br.tolist() if python_floats else list(br))
+        # :250-296 for all histogram sizes and channels at once: every sum below is a sum of
+        # integer-valued doubles (exact in any order), the two divisions are element-wise float64
+        # as in the reference
+        if n_val:
+            k = np.argmin(cal_all @ cur.T, axis=2)             # :281 first min, [hist size, channel]
+            bits = (cur[k] * post_all).sum(axis=2)
+        else:
+            bits = np.zeros((nh, 0))
+        br = bit_rate(bits, n_all, BP)
+        per_hist = [row.tolist() if python_floats else list(row) for row in br]
         stored_BRs.append(per_hist)
         if len(sclvs) != 1:  # :310-316 drop the encoder whose removal hurts the training set least
+            # min over the columns other than r == the row minimum, or the second smallest where
+            # column r holds (the first occurrence of) the minimum; np.mean sees the same vector
+            # of values in the same order as np.mean(np.min(np.delete(dot, r, axis=1), axis=1))
             cost = np.zeros(len(sclvs))
-            for r in range(len(sclvs)):
-                cost[r] = np.mean(np.min(np.delete(dot, r, axis=1), axis=1))
+            if n_train:
+                part = np.partition(dot, 1, axis=1)
+                m1, m2 = part[:, 0], part[:, 1]
+                for r in range(len(sclvs)):
+                    cost[r] = np.mean(np.where(assign == r, m2, m1))
+            else:
+                cost[:] = np.nan
             sclvs = np.delete(sclvs, np.argmin(cost), axis=0)
         else:
             sclvs = np.delete(sclvs, 0, axis=0)
