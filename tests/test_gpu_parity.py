@@ -673,3 +673,43 @@ def test_long_calibration_windows(mh, S, h, mode):
     want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host), nthreads=8)
     assert np.array_equal(out.cpu().numpy(), want)
     plan.close()
+
+
+def test_plan_parameter_grid_is_accepted_or_rejected_cleanly(mh):
+    """Every combination of in- and out-of-range plan parameters either yields an error code (and
+    no plan) or a plan on which measure / encode / decode run to completion."""
+    import ctypes as ct
+    import itertools
+    lib, L = mh._lib.lib(), mh._lib
+    vp = ct.c_void_p
+    rng = np.random.RandomState(0)
+    lens = np.array([1, 5, 70, 20000, 16384 + 64], np.uint64)
+    off = np.concatenate([[0], np.cumsum((lens + 15) // 16 * 16)[:-1]]).astype(np.uint64)
+    data = torch.from_numpy(rng.randint(0, 20, size=int(off[-1] + lens[-1]) + 64).astype(np.uint8)).cuda()
+    out = torch.zeros_like(data)
+    p_ = lambda t: vp(t.data_ptr())
+    accepted = 0
+    for S, h, K, sc, mode, window in itertools.product((1, 2, 10, 11, 17), (0, 6, 30, 31), (0, 1, 36, 300),
+                                                       (0, 2, 64, 100000), (0, 1, 2), (0, 3, 4)):
+        tab = helpers.sclv_tables()[min(max(S, 2), 10)]
+        rows = np.ascontiguousarray(np.concatenate([tab] * (K // len(tab) + 1))[:max(K, 1)])
+        plan = vp()
+        rc = lib.mh_plan_create(ct.byref(plan), off.ctypes.data, lens.ctypes.data, len(lens), S, h, mode, window,
+                                rows.ctypes.data, K, sc)
+        if rc != 0:
+            assert rc in (L.ERR_ARG, L.ERR_SCLV) and not plan.value, (rc, S, h, K, sc, mode, window)
+            continue
+        accepted += 1
+        info = L.PlanInfo()
+        L.check(lib.mh_plan_info(plan, ct.byref(info)))
+        pay = torch.zeros(int(info.payload_cap_words), dtype=torch.int32, device="cuda")
+        segw = torch.zeros(int(info.n_segments) + 1, dtype=torch.int64, device="cuda")
+        chb = torch.zeros(len(lens), dtype=torch.int64, device="cuda")
+        pk = torch.zeros(len(lens), dtype=torch.uint8, device="cuda")
+        en, sk = torch.zeros_like(pk), torch.zeros_like(pk)
+        L.check(lib.mh_measure(plan, p_(data), None, None, None, None, None, p_(chb), None, None))
+        L.check(lib.mh_encode(plan, p_(data), p_(pay), pay.numel(), p_(segw), p_(chb), p_(pk), p_(en), p_(sk), None))
+        L.check(lib.mh_decode(plan, p_(pay), None, p_(pk), p_(en), p_(out), None))
+        torch.cuda.synchronize()
+        lib.mh_plan_destroy(plan)
+    assert accepted > 50
