@@ -235,6 +235,68 @@ __device__ __forceinline__ void overflow_chunk(const uint8_t *src, uint32_t m, c
     dst += words;
 }
 
+// One 16-sample piece per lane (x = 4 dwords of counts) appended to the lane's accumulator: the row
+// body of encode_full_chunk as a function, for the partial-chunk encoder.  (encode_full_chunk keeps its
+// own copy: routing it through this function cost the S=10 kernel 6 % on the same box.)
+// ABL: see encode_full_chunk.
+template <int LC, int PB, int ABL>
+__device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t &acc, uint32_t &nb, uint32_t &sp,
+                                           uint32_t *st, uint32_t cap)
+{
+    constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
+#define MH_FLUSH()                                               \
+    if (nb >= 32) {                                              \
+        if (ABL < 3 && sp < cap) st[sp * 16] = (uint32_t)acc;    \
+        acc >>= 32;                                              \
+        nb -= 32;                                                \
+        ++sp;                                                    \
+    }
+    const uint32_t hi = (x.x | x.y | x.z | x.w) & kHiMask;
+    if (__any(hi != 0)) {  // rare: a count that does not fit PB bits somewhere in this KiB row
+        x.x = clip_word<PB>(x.x);
+        x.y = clip_word<PB>(x.y);
+        x.z = clip_word<PB>(x.z);
+        x.w = clip_word<PB>(x.w);
+    }
+    if (LC >= 2) {
+        // long codes: two dwords (8 codewords) share one accumulator check whenever they fit 32 bits
+        // in every lane of the wave; otherwise dword by dword, and for 9-bit codes pair by pair
+#pragma unroll
+        for (int dp = 0; dp < 2; ++dp) {
+            const uint32_t y0 = pair_index_word<PB>(x[2 * dp]), y1 = pair_index_word<PB>(x[2 * dp + 1]);
+            const uint2 a0 = lut2[y0 & 0xFFu], a1 = lut2[(y0 >> 16) & 0xFFu];
+            const uint2 b0 = lut2[y1 & 0xFFu], b1 = lut2[(y1 >> 16) & 0xFFu];
+            const uint32_t t0 = a0.y + a1.y, t1 = b0.y + b1.y;
+            if (LC == 3 && __builtin_expect(__any(t0 > 32u || t1 > 32u), 0)) {
+                acc |= (uint64_t)a0.x << nb; nb += a0.y; MH_FLUSH();
+                acc |= (uint64_t)a1.x << nb; nb += a1.y; MH_FLUSH();
+                acc |= (uint64_t)b0.x << nb; nb += b0.y; MH_FLUSH();
+                acc |= (uint64_t)b1.x << nb; nb += b1.y; MH_FLUSH();
+            } else if (__any(t0 + t1 > 32u)) {
+                acc |= (uint64_t)(a0.x | (a1.x << a0.y)) << nb; nb += t0; MH_FLUSH();
+                acc |= (uint64_t)(b0.x | (b1.x << b0.y)) << nb; nb += t1; MH_FLUSH();
+            } else {
+                const uint32_t q0 = a0.x | (a1.x << a0.y), q1 = b0.x | (b1.x << b0.y);
+                acc |= (uint64_t)(q0 | (q1 << t0)) << nb;
+                nb += t0 + t1;
+                MH_FLUSH();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t y = pair_index_word<PB>(x[d]);
+            const uint2 e0 = lut2[y & 0xFFu];
+            const uint2 e1 = lut2[(y >> 16) & 0xFFu];
+            const uint32_t q = e0.x | (e1.x << e0.y);
+            acc |= (uint64_t)q << nb;
+            nb += e0.y + e1.y;
+            if ((LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
+        }
+    }
+#undef MH_FLUSH
+}
+
 // One full chunk.  v[] is a rolling window: row k of this chunk sits in v[k & 7]; after it is
 // consumed the slot is refilled with the row 8 KiB further on (this chunk, then the next one).
 // ABL (debug ablation, 0 in production): 1 no global stores, 2 also no merge, 3 also no staging
@@ -328,48 +390,56 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
     merge_and_flush<(LC == 0 ? 4 : 8), ABL>(buf, cap, tot, sp, dst, pend, lane, words, bits);
 }
 
-// Last, partial chunk of a channel (m < 16384 samples): per-symbol front end with validity
-// predicates, same staging and the same in-place merge.
+// Last, partial chunk of a channel (m < 16384 samples).  Its full pieces (16 samples) take the same
+// pair-table row routine as a full chunk -- all their loads issued up front, eight rows at a time --
+// and only the one cut piece (m % 16 samples, in lane (m / 16) % 64, that lane's last piece) goes
+// symbol by symbol.  Same staging and the same in-place merge.
 // Returns {words, bits, new pend, words by which dst advanced}.
-template <int NE>
-__device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ src, uint32_t m,
+template <int LC, int PB>
+__device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ src, uint32_t m, const uint2 *lut2,
                                                    const uint2 *lut1, uint32_t *buf, uint32_t cap,
                                                    uint32_t *__restrict__ dst0, uint32_t pend, int lane)
 {
+    constexpr int NE = LC == 0 ? 4 : 8;
     uint32_t *__restrict__ dst = dst0;
     uint32_t words, bits;
     uint64_t acc = 0;
     uint32_t nb = 0, sp = 0;
     uint32_t *st = stage_lane_base(buf, cap, lane);
+    const uint32_t nfp = m >> 4;               // full pieces
+    const uint32_t nrows = (nfp + 63) >> 6;    // rows holding at least one of them (wave-uniform)
 #pragma unroll 1
-    for (int k = 0; k < kRows; ++k) {
-        const uint32_t base = ((uint32_t)k * kLanes + lane) * MH_PIECE;
-        const int c = (int)m - (int)base;
-        const int cnt = c < 0 ? 0 : (c > MH_PIECE ? MH_PIECE : c);
-        u32x4 x = {0u, 0u, 0u, 0u};
-        if (cnt == MH_PIECE) {
-            x = *reinterpret_cast<const u32x4_u *>(src + base);
-        } else {
+    for (int half = 0; half < 2; ++half) {
+        if ((uint32_t)(half * 8) >= nrows) break;
+        u32x4 v[8];
 #pragma unroll
-            for (int i = 0; i < MH_PIECE; ++i)
-                if (i < cnt) x[i >> 2] |= (uint32_t)src[base + i] << (8 * (i & 3));
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t piece = (uint32_t)(half * 8 + r) * kLanes + lane;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            v[r] = z;
+            if (piece < nfp) v[r] = load_row(src + piece * MH_PIECE);
         }
 #pragma unroll
-        for (int i = 0; i < MH_PIECE; ++i) {
-            if (i < cnt) {
-                uint32_t b = (x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                b = b > 15u ? 15u : b;
-                const uint2 e = lut1[b];
-                acc |= (uint64_t)e.x << nb;
-                nb += e.y;
-            }
-            if ((i + 1) % 3 == 0 || i == MH_PIECE - 1) {  // <= 3 symbols of <= 9 bits between checks
-                if (nb >= 32) {
-                    if (sp < cap) st[sp * 16] = (uint32_t)acc;
-                    acc >>= 32;
-                    nb -= 32;
-                    ++sp;
-                }
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t k = (uint32_t)(half * 8 + r);
+            if (k < nrows && k * kLanes + lane < nfp)  // the escapes inside ballot the active lanes only
+                encode_row<LC, PB, 0>(v[r], lut2, acc, nb, sp, st, cap);
+        }
+    }
+    const uint32_t cnt = m & 15u;
+    if (cnt && (uint32_t)lane == (nfp & 63u)) {  // the cut piece
+        const uint8_t *q = src + nfp * MH_PIECE;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            uint32_t b = q[i];
+            b = b > 15u ? 15u : b;
+            const uint2 e = lut1[b];
+            acc |= (uint64_t)e.x << nb;
+            nb += e.y;
+            if (nb >= 32) {
+                if (sp < cap) st[sp * 16] = (uint32_t)acc;
+                acc >>= 32;
+                nb -= 32;
+                ++sp;
             }
         }
     }
@@ -433,8 +503,8 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
         }
     }
     if (rem) {
-        const uint4 r = encode_partial_chunk<(LC == 0 ? 4 : 8)>(src + (size_t)nfull * kChunk, rem, lut1, buf, cap,
-                                                                 out, pend, lane);
+        const uint4 r = encode_partial_chunk<LC, PB>(src + (size_t)nfull * kChunk, rem, lut2, lut1, buf, cap, out, pend,
+                                                      lane);
         words += r.x;
         bits += r.y;
         pend = r.z;
@@ -543,11 +613,14 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw32, int lane)
 // HY (hybrid pair table, maxlen > W/2): an entry whose second codeword does not fit in the W
 // index bits has bit 31 set and carries one symbol; the second comes from the per-symbol table
 // `tab1` in a branch that whole waves skip (long codewords belong to rare symbols).
-template <int K, int M, int RL, bool HY>
+// PARTIAL: the chunk holds m < 16384 samples.  Rows past the last sample are skipped (wave-uniform),
+// lanes whose piece is not complete skip the row, and the one cut piece (m % 16 samples) is decoded
+// symbol by symbol from the same window.
+template <int K, int M, int RL, bool HY, bool PARTIAL = false>
 __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *tabw, uint32_t maskW,
                                                     const uint8_t *tab1, uint32_t mask1,
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
-                                                    int lane)
+                                                    int lane, uint32_t m = kChunk)
 {
     // Bit window: 64 bits starting at word `wi` of the staged payload, `bp` bits already used.
     // RL (reload): every M lookups the window is simply RE-READ from LDS at the lane's absolute bit
@@ -576,8 +649,32 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
     uint32_t pos = h.P + 32 - SH, wi = pos >> 5, bp = pos & 31;
     uint64_t buf = (uint64_t)stage[wi] | ((uint64_t)stage[wi + 1] << 32);
     uint32_t nxt = kReload ? 0u : stage[wi + 2];
-#pragma unroll
-    for (int k = 0; k < kRows; ++k) {
+    const uint32_t nfp = m >> 4;                   // complete pieces (PARTIAL)
+    const uint32_t nrows_any = (m + 1023u) >> 10;  // rows holding any sample (PARTIAL)
+    auto row = [&](int k) {
+        const uint32_t piece = (uint32_t)k * kLanes + lane;
+        if (PARTIAL && piece >= nfp) {
+            if (piece == nfp && (m & 15u)) {  // the cut piece: m % 16 symbols, one lane of the chunk
+                uint8_t *q = out + piece * MH_PIECE;
+                for (uint32_t i = 0; i < (m & 15u); ++i) {
+                    const uint32_t e1 = tab1[(uint32_t)(buf >> (bp + SH)) & mask1];
+                    q[i] = (uint8_t)(e1 & 15u);
+                    bp += e1 >> 4;
+                    if (kReload) {
+                        pos += e1 >> 4;
+                        const uint32_t w_ = pos >> 5;
+                        buf = (uint64_t)stage[w_] | ((uint64_t)stage[w_ + 1] << 32);
+                        bp = pos & 31;
+                    } else if (bp >= 32) {
+                        buf = (buf >> 32) | ((uint64_t)nxt << 32);
+                        bp -= 32;
+                        ++wi;
+                        nxt = stage[wi + 2];
+                    }
+                }
+            }
+            return;
+        }
         u32x4 o;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -633,7 +730,60 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
             o[d] = w;
         }
         __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + ((uint32_t)k * kLanes + lane) * MH_PIECE));
+    };
+    if (PARTIAL) {  // a rolled loop keeps the rarely run instance small (registers and code)
+#pragma unroll 1
+        for (int k = 0; k < (int)nrows_any; ++k) row(k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) row(k);
     }
+}
+
+// Last, partial chunk of a segment through the same staged machinery: header (two dependent
+// reads of this chunk's own words), the whole payload copied to LDS in one batch of loads, then
+// decode_staged_chunk<PARTIAL>.  A chunk too large for the staging area takes the per-symbol
+// routine on global memory.
+template <int K, int M, int RL, bool HY>
+__device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict__ in, uint32_t m, const uint32_t *tabw,
+                                                  uint32_t maskW, const uint8_t *tab1, uint32_t mask1,
+                                                  uint32_t *stage, uint32_t cap_words, uint8_t *__restrict__ out,
+                                                  int lane)
+{
+    const uint32_t w0 = in[0];
+    const uint32_t mn = w0 & 0xFFFu, hwid = (w0 >> 12) & 15u;
+    uint32_t len = mn;
+    if (hwid) {
+        const uint32_t fb = 16u + (uint32_t)lane * hwid;
+        uint64_t v = in[fb >> 5];
+        if ((fb & 31) + hwid > 32) v |= (uint64_t)in[(fb >> 5) + 1] << 32;
+        len += (uint32_t)(v >> (fb & 31)) & ((1u << hwid) - 1u);
+    }
+    const uint32_t incl = wave_scan_incl(len, lane);
+    ChunkHdr h;
+    h.P = incl - len;
+    h.nw = (__shfl(incl, 63, 64) + 31) >> 5;
+    h.hw = hdr_words(hwid);
+    const uint32_t ns = h.nw + 3;
+    if (ns > cap_words) {
+        decode_chunk<3, false>(in, m, tab1, mask1, out, lane);
+        return;
+    }
+    const uint32_t *pay = in + h.hw;
+    for (uint32_t j0 = 0; j0 < ns; j0 += 8 * 64) {
+        uint32_t r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = j0 + (uint32_t)j * 64 + lane;
+            if (j0 + (uint32_t)j * 64 < ns) r[j] = pay[i < ns ? i : ns - 1];  // never past nw + 2
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j0 + (uint32_t)j * 64 < ns) stage[j0 + (uint32_t)j * 64 + lane] = r[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    decode_staged_chunk<K, M, RL, HY, true>(h, tabw, maskW, tab1, mask1, stage, out, lane, m);
 }
 
 // NR payload registers per lane: the next chunk's payload (up to NR*64 words) is fetched into
@@ -736,7 +886,7 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
         }
         in = pay + cur.nw;  // first word after the last full chunk
     }
-    if (rem) decode_chunk<3, false>(in, rem, tab1, mask1, out + (size_t)nfull * kChunk, lane);
+    if (rem) decode_partial_chunk<K, M, RL, HY>(in, rem, tab, maskW, tab1, mask1, stage, kCap, out + (size_t)nfull * kChunk, lane);
 }
 
 // ------------------------------------------------------------------------------------------
