@@ -187,6 +187,9 @@ def test_unaligned_buffer_and_many_encoders(mh):
     (10, 0, "bursts", [[1, 2, 3, 4, 5, 6, 7, 8, 9, 9]]),
     (8, 0, "bursts", [[1, 2, 3, 4, 5, 6, 7, 7]]),
     (10, 1, "bursts", None),
+    # odd sub-streams all 9-bit codewords, even ones all 1-bit: lengths 2304 vs 256 -> the widest header
+    # field (12 bits, 25 header words), written by the global slow path
+    (10, 0, "lanes", [[1, 2, 3, 4, 5, 6, 7, 8, 9, 9]]),
 ])
 def test_slow_paths_for_incompressible_data(mh, S, mode, gen, rows):
     """Data that needs > 3 bits/sample overflows the capped LDS staging (encoder) and the staged
@@ -195,6 +198,8 @@ def test_slow_paths_for_incompressible_data(mh, S, mode, gen, rows):
     lens = [16384 * 3, 16384 + 5000, 70001, 16384, 100, 40000]
     if gen == "uniform":
         chans = [rng.randint(0, 13, size=T).astype(np.uint8) for T in lens]
+    elif gen == "lanes":
+        chans = [np.where((np.arange(T) >> 4) & 1, 9, 0).astype(np.uint8) for T in lens]
     elif gen == "bursts":
         chans = []
         for T in lens:
