@@ -190,6 +190,9 @@ def test_unaligned_buffer_and_many_encoders(mh):
     # odd sub-streams all 9-bit codewords, even ones all 1-bit: lengths 2304 vs 256 -> the widest header
     # field (12 bits, 25 header words), written by the global slow path
     (10, 0, "lanes", [[1, 2, 3, 4, 5, 6, 7, 8, 9, 9]]),
+    # 20 of the 64 sub-streams long: written by the slow path, but the chunk (1792 words) fits the
+    # decoder's staging, so the 12-bit fields are read by the fast decoder's shuffles
+    (10, 0, "lanes20", [[1, 2, 3, 4, 5, 6, 7, 8, 9, 9]]),
 ])
 def test_slow_paths_for_incompressible_data(mh, S, mode, gen, rows):
     """Data that needs > 3 bits/sample overflows the capped LDS staging (encoder) and the staged
@@ -200,6 +203,8 @@ def test_slow_paths_for_incompressible_data(mh, S, mode, gen, rows):
         chans = [rng.randint(0, 13, size=T).astype(np.uint8) for T in lens]
     elif gen == "lanes":
         chans = [np.where((np.arange(T) >> 4) & 1, 9, 0).astype(np.uint8) for T in lens]
+    elif gen == "lanes20":
+        chans = [np.where(((np.arange(T) >> 4) & 63) < 20, 9, 0).astype(np.uint8) for T in lens]
     elif gen == "bursts":
         chans = []
         for T in lens:
