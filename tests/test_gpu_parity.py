@@ -508,6 +508,33 @@ def test_calibrate_then_stream_protocol(mh):
             assert int(c.ch_bits[ch]) == int(lens.sum()), ch
 
 
+def test_stream_slots_are_reused_and_follow_recalibration(mh):
+    """Blocks of two shapes alternate (cached plans and buffers are reused), then the encoder is
+    re-calibrated on very different data: later blocks must be coded with the NEW word."""
+    from muahuff import stream
+    rng = np.random.RandomState(32)
+    C, S = 20, 4
+    tab = helpers.sclv_tables()[S]
+    se = stream.StreamEncoder(C, S, 5, tab)
+    lo = lambda T: np.minimum(rng.poisson(0.1, size=(T, C)), 255).astype(np.uint8)
+    hi = lambda T: (3 - np.minimum(rng.poisson(0.3, size=(T, C)), 3)).astype(np.uint8)  # peak at symbol 3
+    p1 = se.calibrate(lo(64))[0].cpu().numpy().copy()
+    for T in (3000, 777, 3000, 777, 3000):
+        x = lo(T)
+        c = se.encode_block(x)
+        assert np.array_equal(c.peak, p1)
+        assert np.array_equal(stream.StreamEncoder.decode_block(c), np.minimum(x, S - 1))
+    assert sorted(se._slots) == [777, 3000]
+    p2 = se.calibrate(hi(64))[0].cpu().numpy().copy()
+    assert not se._slots and (p2 == 3).all() and not np.array_equal(p1, p2)
+    for T in (3000, 777):
+        x = hi(T)
+        c = se.encode_block(x)
+        assert np.array_equal(c.peak, p2)
+        assert np.array_equal(stream.StreamEncoder.decode_block(c), np.minimum(x, S - 1))
+    se.close()
+
+
 def test_package_level_api_matches_golden(mh, tmp_path):
     """muahuff.bit_rates reproduces the reference's per-channel BRs of the golden fixture, and
     muahuff.compress / decompress round-trip through a file."""
