@@ -13,13 +13,22 @@ per-GPU work (weak scaling; configs[3]'s 10 000-channel set is 1250 channels/GPU
 gather that concatenates the packed bitstream is run once after the timed region and
 reported separately under "gather".
 
+Launching: with --gpus N > 1 and no WORLD_SIZE in the environment this process becomes a
+launcher -- before any GPU call it starts N ranks (python -m torch.distributed.run, one per
+GPU, rendezvous on 127.0.0.1), relays their output and exits with their worst status.  Under
+torchrun (WORLD_SIZE set) it is a rank.  A failed or stuck gather is recorded in the JSON line
+AND turns the exit status non-zero.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-"roofline" (dominant kernel against the 8 TB/s HBM peak) and "cpu_baseline" (the CPU oracle
-timed on a bounded sample on this host's cores).
+"roofline" (dominant kernel against the 8 TB/s HBM peak, plus per_S: every dynamic range of
+the reference's sweep) and "cpu_baseline" (the CPU oracle timed on a bounded sample on this
+host's cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,13 +39,16 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+RC_GATHER_STUCK, RC_GATHER_FAILED, RC_BAD_LAUNCH = 3, 4, 2
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=250, help="default keeps the timed region above one second")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels-per-gpu", type=int, default=1024)
     ap.add_argument("--bins", type=int, default=10_000_000)
     ap.add_argument("--S", type=int, default=3)
@@ -47,13 +59,45 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-channels", type=int, default=96)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-per-S", action="store_true", help="skip the per-dynamic-range sweep (roofline.per_S)")
+    ap.add_argument("--no-small-shape", action="store_true", help="skip the short-channel extra (small_shape)")
     ap.add_argument("--gather-deadline", type=int, default=90, help="seconds allowed for the untimed payload gather")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="ranks rendezvous, barrier and report; no codec work and no metric (launcher self-test, runs without a GPU)")
     ap.add_argument("--verify", action="store_true", help="round-trip check after the timed region")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ---- launcher ------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves.  Nothing here touches the GPU
+    (torch.cuda.device_count() does not initialise HIP on this image), and the ranks are CHILD
+    processes -- this process is never replaced."""
+    if a.dist_backend == "nccl":
+        ndev = torch.cuda.device_count()
+        if ndev < a.gpus:
+            sys.stderr.write("bench.py: --gpus %d needs %d visible GPUs, this box has %d (RCCL runs one rank per GPU; "
+                             "--dist-backend gloo only rehearses the control flow)\n" % (a.gpus, a.gpus, ndev))
+            return RC_BAD_LAUNCH
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- helpers -------------------------------------------------------------------------------------
 def cpu_baseline(cs_host, ch_off, ch_len, S, h, mode, tab, seg_chunks, n_ch):
     """The CPU oracle (oracle/mh_oracle.c, kind "port") timed on the first n_ch channels of the
     same workload: 1 thread, then all host cores.  Checker code used as a reported baseline
@@ -99,31 +143,127 @@ def cpu_model():
 def pmc_traffic(kernel, C, T, S, h, seg_chunks):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE cannot be collected while timing; they come from separate --pmc runs of this
-    same command, profiles/r01_pmc_traffic.json).  None when the workload differs."""
-    fn = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(fn) as f:
-            d = json.load(f)
-        w = d["workload"]
-        if (w["channels_per_gpu"], w["bins"], w["S"], w["hist_bits"], w["seg_chunks"]) != (C, T, S, h, seg_chunks):
-            return None, None
-        return d["kernels"][kernel]["hbm_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, gfx950 FETCH x2)"
-    except (OSError, KeyError, ValueError):
-        return None, None
+    same command, tools/collect_pmc_traffic.sh).  None when the workload differs."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            w = d["workload"]
+            if (w["channels_per_gpu"], w["bins"], w["S"], w["hist_bits"], w["seg_chunks"]) != (C, T, S, h, seg_chunks):
+                continue
+            return d["kernels"][kernel]["hbm_bytes"], "profiles/%s (rocprofv3 --pmc, gfx950 FETCH x2)" % name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def main():
-    a = parse()
+def event_times(fn, reps, warm=2):
+    """ms per call of fn() (enqueues work on torch's current stream), one HIP event pair per call."""
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a_, b_ in ev:
+        a_.record()
+        fn()
+        b_.record()
+    torch.cuda.synchronize()
+    return [a_.elapsed_time(b_) for a_, b_ in ev]
+
+
+def stats(ms):
+    v = np.asarray(ms, dtype=np.float64)
+    return {"min": float(v.min()), "median": float(np.median(v)), "mean": float(v.mean()), "max": float(v.max())}
+
+
+def per_S_sweep(cs, out, h, mode, seg_chunks, reps=5):
+    """Encode / decode of the same resident batch at every dynamic range of the reference's sweep
+    (S = 2..10 with all K encoders of that S, get_BR_with_approx_sort.py:107,120-125): event-timed
+    ops against their algorithmic bytes.  Outside the timed region."""
+    import muahuff
+    from muahuff import codec, sclv
+    rows = []
+    for S in range(2, 11):
+        tab = sclv.table(S)
+        plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, mode, muahuff.WIN_AFTER_CAL, tab, seg_chunks=seg_chunks)
+        enc = plan.alloc_encoded()
+        e_ms = event_times(lambda: plan.encode(cs.data, out=enc), reps)
+        d_ms = event_times(lambda: plan.decode(enc, out), reps)
+        n = plan.window_samples
+        b = float(enc.ch_bits.sum().item()) / n
+        ab = n * (1.0 + b / 8.0)
+        em, dm = float(np.median(e_ms)), float(np.median(d_ms))
+        rows.append({"S": S, "K": int(tab.shape[0]), "bits_per_sample": b, "encode_ms": em, "decode_ms": dm,
+                     "encode_GBps": ab / em / 1e6, "decode_GBps": ab / dm / 1e6,
+                     "encode_frac": ab / em / 1e6 / HBM_PEAK_GBS, "decode_frac": ab / dm / 1e6 / HBM_PEAK_GBS})
+        plan.close()
+        del enc
+    return rows
+
+
+def small_shape(S, h, mode, seg_chunks, reps=20):
+    """The reference's real shape: 50 ms bins give 2e4-7e4 samples per channel
+    (Data/get_all_binned_data.py:16; training set ~2400 channels, get_BR_with_approx_sort.py:24,89-90).
+    2400 channels x 72 000 bins, same design point, event-timed ops.  Not the headline."""
+    import muahuff
+    from muahuff import codec, sclv, synth
+    C, T = 2400, 72_000
+    tab = sclv.table(S)
+    cs = synth.generate(C, T, seed=5)
+    plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, mode, muahuff.WIN_AFTER_CAL, tab, seg_chunks=seg_chunks)
+    enc = plan.alloc_encoded()
+    out = torch.empty_like(cs.data)
+    e_ms = event_times(lambda: plan.encode(cs.data, out=enc), reps, warm=3)
+    d_ms = event_times(lambda: plan.decode(enc, out), reps, warm=3)
+    n = plan.window_samples
+    b = float(enc.ch_bits.sum().item()) / n
+    ab = n * (1.0 + b / 8.0)
+    em, dm = float(np.median(e_ms)), float(np.median(d_ms))
+    plan.close()
+    return {"workload": "2400 channels x 72 000 bins (50 ms bins), S=%d, 2^%d calibration" % (S, h),
+            "samples": n, "bits_per_sample": b, "encode_us": em * 1e3, "decode_us": dm * 1e3,
+            "encode_GBps": ab / em / 1e6, "decode_GBps": ab / dm / 1e6,
+            "encode_frac": ab / em / 1e6 / HBM_PEAK_GBS, "decode_frac": ab / dm / 1e6 / HBM_PEAK_GBS,
+            "timing": "HIP events around each op (calibrate/table kernel + codec kernel), median of %d" % reps}
+
+
+# ---- one rank ------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1) if a.dist_backend == "gloo" else local
-    torch.cuda.set_device(local)
+    if a.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch N ranks with `python bench.py --gpus N` (it starts "
+                         "them itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`\n"
+                         % (a.gpus, world))
+        sys.exit(RC_BAD_LAUNCH)
     dist = None
     coll_dev = "cuda" if a.dist_backend == "nccl" else "cpu"
+    if a.check_launch:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+            ok = float(t.item()) == world * (world - 1) / 2
+            n_ranks = dist.get_world_size()
+            dist.destroy_process_group()
+        else:
+            ok, n_ranks = True, 1
+        if rank == 0:
+            print(json.dumps({"check_launch": bool(ok), "n_gpus": world, "ranks": n_ranks}), flush=True)
+        sys.exit(0 if ok else RC_BAD_LAUNCH)
+    ndev = torch.cuda.device_count()
+    if a.dist_backend == "nccl" and world > ndev:
+        sys.stderr.write("bench.py: %d ranks but %d visible GPUs (one rank per GPU with RCCL)\n" % (world, ndev))
+        sys.exit(RC_BAD_LAUNCH)
+    local = local % max(ndev, 1) if a.dist_backend == "gloo" else local
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -173,36 +313,33 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    devices = None
+    if dist is not None:
+        devices = [None] * world
+        dist.all_gather_object(devices, "%s cuda:%d" % (torch.cuda.get_device_name(local), local))
 
     # auxiliary, outside the timed region: mh_measure on the same resident batch with the
     # reference's own window rule [c, c+T/2) -- the only thing the reference itself computes
     plan_m = codec.Plan(cs.ch_off, cs.ch_len, S, h, a.mode, muahuff.WIN_REF_HALF, tab)
     meas = plan_m.measure(cs.data)
-    torch.cuda.synchronize()
-    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    m0.record()
-    for _ in range(3):
-        plan_m.measure(cs.data, out=meas)
-    m1.record()
-    torch.cuda.synchronize()
-    meas_ms = m0.elapsed_time(m1) / 3
+    meas_ms = float(np.median(event_times(lambda: plan_m.measure(cs.data, out=meas), 5, warm=1)))
     meas_samples = plan_m.window_samples
     ref_bits_per_sample = float(meas.bits.sum().item()) / max(meas_samples, 1)
     plan_m.close()
 
-    enc_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(a.steps)]))
-    dec_ms = float(np.mean([ev[i][1].elapsed_time(ev[i][2]) for i in range(a.steps)]))
+    enc_all = [ev[i][0].elapsed_time(ev[i][1]) for i in range(a.steps)]
+    dec_all = [ev[i][1].elapsed_time(ev[i][2]) for i in range(a.steps)]
+    enc_ms, dec_ms = float(np.mean(enc_all)), float(np.mean(dec_all))
     bits = int(enc.ch_bits.sum().item())
     words = int(enc.seg_words.sum().item())
     b = bits / samples                 # payload bits/sample (== the reference's histogram.SCLV)
     cb = words * 32 / samples          # container bits/sample (headers + padding included)
 
-    gather = None
-    gather_hung = False
+    gather, rc = None, 0
     if dist is not None and not a.no_gather:
         # Untimed extra: concatenate the packed bitstreams on rank 0 (RCCL point-to-point over
-        # xGMI).  Run under a deadline in a helper thread so that a stuck collective can never
-        # cost the run its JSON line.
+        # xGMI; device tensors end to end).  Run under a deadline in a helper thread so that a
+        # stuck collective can never cost the run its JSON line -- but it does cost the exit status.
         import threading
         from muahuff import dist as mdist
         box = {}
@@ -216,16 +353,16 @@ def main():
             pay, offs = mdist.gather_payload(src, int(tot.item()), dst=0)
             barrier()
             g = time.perf_counter() - g0
-            box["v"] = dict(ms=g * 1e3, bytes_total=int(offs[-1]) * 4,
+            box["v"] = dict(ms=g * 1e3, bytes_total=int(offs[-1]) * 4, payload_device=str(src.device),
                             GBps_into_root=(int(offs[-1]) - int(offs[1])) * 4 / g / 1e9)
             del pay, src, dense
-            # the same gather pipelined behind the encoder: 4 channel blocks per rank, block b is on
-            # the wire while block b+1 encodes (dist.gather_payload_pipelined)
+            # the same gather pipelined behind the encoder: 4 channel blocks per rank, block b is on the
+            # wire while block b+1 encodes (dist.gather_payload_pipelined); every block has its own buffers
             try:
                 nblk = 4
                 plans, encs, bufs = [], [], []
-                for b in range(nblk):
-                    b0, b1 = mdist.shard_channels(C, nblk, b)
+                for k in range(nblk):
+                    b0, b1 = mdist.shard_channels(C, nblk, k)
                     pb = codec.Plan(cs.ch_off[b0:b1], cs.ch_len[b0:b1], S, h, a.mode, muahuff.WIN_AFTER_CAL, tab,
                                     seg_chunks=a.seg_chunks)
                     plans.append(pb)
@@ -249,14 +386,24 @@ def main():
                                              bytes_total=int(offs2[-1, 0]) * 4)
                 for pb in plans:
                     pb.close()
-            except Exception as e:  # the plain gather above stands
+            except Exception as e:  # the plain gather above stands; the failure is reported and fails the run
                 box["v"]["pipelined"] = {"error": repr(e)}
+                box["rc"] = RC_GATHER_FAILED
 
-        th = threading.Thread(target=do_gather, daemon=True)
+        def guarded():
+            try:
+                do_gather()
+            except Exception as e:
+                box.setdefault("v", {})["error"] = repr(e)
+                box["rc"] = RC_GATHER_FAILED
+
+        th = threading.Thread(target=guarded, daemon=True)
         th.start()
         th.join(a.gather_deadline)
-        gather_hung = th.is_alive()
-        gather = box.get("v") if not gather_hung else {"error": "gather did not finish within %ds" % a.gather_deadline}
+        if th.is_alive():
+            gather, rc = {"error": "gather did not finish within %ds" % a.gather_deadline}, RC_GATHER_STUCK
+        else:
+            gather, rc = box.get("v"), box.get("rc", 0)
 
     ok = None
     if a.verify:
@@ -271,12 +418,23 @@ def main():
         value = total_samples * a.steps / dt / 1e6
         # dominant kernel = the slower of the two ops of a step
         if enc_ms >= dec_ms:
-            kname, kms, abytes = "k_encode2", enc_ms, samples * (1.0 + b / 8.0)
+            kname, kms, abytes, kall = "k_encode2", enc_ms, samples * (1.0 + b / 8.0), enc_all
         else:
-            kname, kms, abytes = "k_decode2", dec_ms, samples * (b / 8.0 + 1.0)
+            kname, kms, abytes, kall = "k_decode2", dec_ms, samples * (b / 8.0 + 1.0), dec_all
         achieved = abytes / (kms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(kname, C, T, S, h, a.seg_chunks)
         info = muahuff.device_info(local)
+        roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79%)"
+                "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0,
+                "traffic_source": traffic_src, "algorithmic_bytes": abytes,
+                "algorithmic_bytes_per_sample": abytes / samples,
+                "op_ms": stats(kall),
+                "frac_best_step": abytes / (min(kall) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "timing": "HIP events on the launch stream around the op (calibrate + codec kernel), mean over the timed steps"}
+        if not a.no_per_S and world == 1:
+            roof["per_S"] = per_S_sweep(cs, out, h, a.mode, a.seg_chunks)
         line = {
             "metric": "MSamples/s encode+decode (static-Huffman MUA codec)",
             "value": value, "unit": "MSamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -291,24 +449,25 @@ def main():
                                 # the reference's figure of merit for the same bits (get_BR_with_approx_sort.py:289-292)
                                 # if these were 50 ms bins: BR = 1000 / (BP / bits_per_sample)
                                 "BR_bits_per_s_per_channel_at_BP50": float(codec.bit_rate(bits, samples, 50))},
-            "kernels_ms": {"encode_op": enc_ms, "decode_op": dec_ms,
+            "kernels_ms": {"encode_op": enc_ms, "decode_op": dec_ms, "encode_op_stats": stats(enc_all),
+                           "decode_op_stats": stats(dec_all),
                            "encode_MSamples_s": samples / enc_ms / 1e3, "decode_MSamples_s": samples / dec_ms / 1e3,
                            "measure_op": meas_ms, "measure_MSamples_s": meas_samples / meas_ms / 1e3,
                            "measure_GBps": meas_samples / meas_ms / 1e6,
                            "measure_window": "[c, c+T/2) reference rule, bits/sample %.4f" % ref_bits_per_sample},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79%)"
-                         "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0,
-                         "traffic_source": traffic_src, "algorithmic_bytes": abytes,
-                         "algorithmic_bytes_per_sample": abytes / samples,
-                         "timing": "HIP events on the launch stream around the op (calibrate+memset+kernel)"},
+            "roofline": roof,
             "device": info["name"] + " " + info["arch"],
         }
+        if dist is not None:
+            line["rccl_ranks"] = dist.get_world_size()
+            line["dist_backend"] = a.dist_backend
+            line["rank_devices"] = devices
         if gather:
             line["gather"] = gather
         if ok is not None:
             line["verified_roundtrip"] = ok
+        if not a.no_small_shape and world == 1:
+            line["small_shape"] = small_shape(S, h, a.mode, a.seg_chunks)
         if not a.no_cpu_baseline and world == 1:
             nch = min(a.cpu_sample_channels, C)
             nbytes = int(cs.ch_off[nch - 1] + cs.ch_len[nch - 1]) + 64
@@ -322,11 +481,14 @@ def main():
                                     "numpy_measure_msamples_s": res["numpy_measure_msamples_s"],
                                     "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
         print(json.dumps(line), flush=True)
-    if gather_hung:
-        sys.stdout.flush()
-        os._exit(0)  # a collective is stuck: the line is out, leave without joining it
+    sys.stdout.flush()
+    if rc == RC_GATHER_STUCK:
+        os._exit(rc)  # a collective is stuck: the line is out, leave without joining it -- and fail
     if dist is not None:
         dist.destroy_process_group()
+    if ok is False:
+        rc = rc or 5
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -94,6 +94,37 @@ class ChannelSet:
                                             ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out
 
+    def rebin(self, r, saturate=True):
+        """Sum ``r`` consecutive bins of every channel on the GPU (mh_rebin): one 1 ms recording
+        feeds all of the reference's bin periods (Data/Load_and_bin_Sabes_store_as_mat_file.m:50-54
+        bins at 1, 5, 10, 20, 50, 100 ms; Compressing data/functions_1.py:11-24).  The last,
+        partial bin is kept (ceil).  saturate=True returns a uint8 ChannelSet whose sums clamp at
+        255 like MATLAB's uint8(); saturate=False returns (int32 tensor, offsets, lengths) with the
+        exact sums."""
+        import ctypes as ct
+
+        from . import _lib
+        r = int(r)
+        nb = (self.ch_len + np.uint64(r - 1)) // np.uint64(r)
+        dev = self.data.device
+        d_off = torch.from_numpy(self.ch_off.astype(np.int64)).to(dev)
+        d_len = torch.from_numpy(self.ch_len.astype(np.int64)).to(dev)
+        vp = ct.c_void_p
+        st = vp(torch.cuda.current_stream().cuda_stream)
+        max_len = int(self.ch_len.max()) if self.C else 0
+        if saturate:
+            out = ChannelSet.empty([int(n) for n in nb], device=dev)
+            o_off = torch.from_numpy(out.ch_off.astype(np.int64)).to(dev)
+            _lib.check(_lib.lib().mh_rebin(vp(self.data.data_ptr()), vp(d_off.data_ptr()), vp(d_len.data_ptr()), self.C,
+                                           max_len, r, 1, vp(out.data.data_ptr()), vp(o_off.data_ptr()), st))
+            return out
+        off = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int64) if self.C else np.zeros(0, np.int64)
+        out = torch.zeros(int(nb.sum()) + 4, dtype=torch.int32, device=dev)
+        o_off = torch.from_numpy(off).to(dev)
+        _lib.check(_lib.lib().mh_rebin(vp(self.data.data_ptr()), vp(d_off.data_ptr()), vp(d_len.data_ptr()), self.C,
+                                       max_len, r, 0, vp(out.data_ptr()), vp(o_off.data_ptr()), st))
+        return out, off, nb.astype(np.int64)
+
     def to_channels(self):
         host = self.data.cpu().numpy()
         return [host[int(o):int(o) + int(n)].copy() for o, n in zip(self.ch_off, self.ch_len)]
