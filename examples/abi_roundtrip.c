@@ -105,7 +105,7 @@ int main(int argc, char **argv)
 
     MH(mh_measure(plan, d_data, NULL, NULL, NULL, NULL, d_post, d_bits, NULL, NULL));
     MH(mh_encode(plan, d_data, d_pay, info.payload_cap_words, d_segw, d_chbits, d_peak, d_enc, d_skip, NULL));
-    MH(mh_decode(plan, d_pay, NULL, d_peak, d_enc, d_out, NULL));
+    MH(mh_decode(plan, d_pay, info.payload_cap_words, NULL, d_peak, d_enc, d_out, NULL));
     HIP(hipDeviceSynchronize());
 
     uint8_t *x = malloc(total + 16), *y = malloc(total + 16);
@@ -138,7 +138,7 @@ int main(int argc, char **argv)
     HIP(hipMalloc((void **)&d_dense, info.payload_cap_words * 4));
     MH(mh_compact(plan, d_pay, d_segw, d_dense, info.payload_cap_words, d_doff, d_total, NULL));
     HIP(hipMemset(d_out, 0xEE, total + 16));
-    MH(mh_decode(plan, d_dense, d_doff, d_peak, d_enc, d_out, NULL));
+    MH(mh_decode(plan, d_dense, info.payload_cap_words, d_doff, d_peak, d_enc, d_out, NULL));
     HIP(hipDeviceSynchronize());
     HIP(hipMemcpy(&total_words, d_total, 8, hipMemcpyDeviceToHost));
     HIP(hipMemcpy(y, d_out, total, hipMemcpyDeviceToHost));

@@ -3,10 +3,10 @@ import ctypes as ct
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.environ.get("MUAHUFF_LIB", os.path.join(HERE, "libmuahuff.so"))  # override: A/B builds only
+SO = os.path.join(HERE, "libmuahuff.so")
 
 MH_OK = 0
-ERR_ARG, ERR_EMPTY_CHANNEL, ERR_SCLV, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+ERR_ARG, ERR_EMPTY_CHANNEL, ERR_SCLV, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_STREAM = -1, -2, -3, -4, -5, -6, -7
 
 MODE_NOSORT, MODE_APPROX = 0, 1
 WIN_REF_HALF, WIN_REF_HALF_TRUNC, WIN_AFTER_CAL, WIN_FULL = 0, 1, 2, 3
@@ -44,7 +44,12 @@ PROTOTYPES = {
     "mh_measure": (_int, [_vp] * 10),
     "mh_encode": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mh_encode_preset": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
-    "mh_decode": (_int, [_vp] * 7),
+    "mh_plan_query": (_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, ct.POINTER(PlanInfo), _vp, _vp, _vp, _vp, _u64]),
+    "mh_decode": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "mh_decode_status": (_int, [_vp, ct.POINTER(_u32), _vp]),
+    "mh_validate_stream": (_int, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "mh_power_draws": (_int, [_vp, _u32, _vp, _u32, _u64, ct.c_double, ct.c_double, ct.c_double, _vp, _u64, _vp]),
+    "mh_reduce_rows": (_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "mh_compact": (_int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     "mh_synth_poisson": (_int, [_vp, _vp, _vp, _u32, _u64, _vp, _u64, _vp]),
     "mh_rebin": (_int, [_vp, _vp, _vp, _u32, _u64, _u32, _int, _vp, _vp, _vp]),
@@ -57,6 +62,15 @@ PROTOTYPES = {
 }
 
 _lib = None
+
+
+def use_library(path):
+    """Load the kernels from another build of libmuahuff.so (same-box A/B runs in tools/).  Must be
+    called before the first use; there is no environment override."""
+    global SO, _lib
+    if _lib is not None:
+        raise RuntimeError("libmuahuff.so is already loaded")
+    SO = str(path)
 
 
 def lib():

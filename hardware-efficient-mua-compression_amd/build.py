@@ -11,7 +11,8 @@ ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libmuahuff.so")
 SOURCES = ["csrc/muahuff.hip"]
 HEADERS = ["csrc/mh_kernels.hpp", "csrc/mh_device.hpp", "csrc/mh_codec2.hpp", "csrc/mh_layout.hpp",
-           "../include/muahuff.h"]
+           "csrc/mh_planner.hpp", "csrc/mh_analysis.hpp", "../include/muahuff.h"]
+TUNING_SO = os.path.join(HERE, "libmuahuff_tuning.so")  # -DMH_TUNING: env knobs + ablation hook, tools/ only
 
 
 def stale():
@@ -21,17 +22,27 @@ def stale():
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
+def build(force=False, verbose=False, tuning=False):
+    """libmuahuff.so -- or, with tuning=True, libmuahuff_tuning.so: the same kernels plus the
+    A/B knobs (MH_DEC_W, MH_DEC_NR, MH_WAVE_TASKS, mhdbg_set_ablation) that the production
+    library does not contain; tools/ load it through _lib.use_library()."""
+    so = TUNING_SO if tuning else SO
+    if tuning:
+        if not force and os.path.exists(so) and not any(
+                os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(so) for f in SOURCES + HEADERS):
+            return so
+    elif not force and not stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
-    cmd += [os.path.join(HERE, s) for s in SOURCES] + ["-o", SO]
+    if tuning:
+        cmd.append("-DMH_TUNING")
+    cmd += [os.path.join(HERE, s) for s in SOURCES] + ["-o", so]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=HERE)
-    return SO
+    return so
 
 
 def build_example(force=False):

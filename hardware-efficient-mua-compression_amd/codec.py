@@ -56,7 +56,8 @@ class Plan:
     """One design point (S, h, mapper, window rule, K candidate encoders) over one channel
     layout.  Mirrors mh_plan_* of include/muahuff.h."""
 
-    def __init__(self, ch_off, ch_len, S, h, mode, window, sclv, seg_chunks=2):
+    def __init__(self, ch_off, ch_len, S, h, mode, window, sclv, seg_chunks=0):
+        """seg_chunks: chunks per segment; 0 = the planner's choice (info.seg_chunks tells)."""
         _need_gpu()
         self.ch_off = np.ascontiguousarray(ch_off, dtype=np.uint64)
         self.ch_len = np.ascontiguousarray(ch_len, dtype=np.uint64)
@@ -75,6 +76,7 @@ class Plan:
         _lib.check(_lib.lib().mh_plan_info(self._h, ct.byref(info)))
         self.info = info
         self.C, self.S = int(info.C), int(info.S)
+        self.seg_chunks = int(info.seg_chunks)
         self.n_segments = int(info.n_segments)
         self.payload_cap_words = int(info.payload_cap_words)
         self.window_samples = int(info.window_samples)
@@ -138,10 +140,18 @@ class Plan:
         return e
 
     def decode(self, enc, out):
-        """out: uint8 tensor with the plan's channel layout; window bytes are overwritten."""
-        _lib.check(_lib.lib().mh_decode(self._h, _ptr(enc.payload), _ptr(enc.seg_off), _ptr(enc.peak),
-                                        _ptr(enc.enc), _ptr(out), _stream()))
+        """out: uint8 tensor with the plan's channel layout; window bytes are overwritten.  The
+        kernel never reads outside enc.payload whatever it holds (decode_ok() tells afterwards
+        whether it had to abandon a segment)."""
+        _lib.check(_lib.lib().mh_decode(self._h, _ptr(enc.payload), enc.payload.numel(), _ptr(enc.seg_off),
+                                        _ptr(enc.peak), _ptr(enc.enc), _ptr(out), _stream()))
         return out
+
+    def decode_ok(self):
+        """True when the last decode() on this plan stayed inside its payload (synchronises)."""
+        flags = ct.c_uint32(0)
+        _lib.check(_lib.lib().mh_decode_status(self._h, ct.byref(flags), _stream()))
+        return flags.value == 0
 
     def compact(self, enc, dense=None, off=None, tot=None):
         """Pack the used words of all segments back to back (for storage / the RCCL gather).

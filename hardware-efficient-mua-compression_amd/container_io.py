@@ -109,9 +109,9 @@ def make_header(S, h, mode, window, seg_chunks, sclv):
 
 
 # ---- GPU end-to-end ----------------------------------------------------------------------------
-def compress(cs, S, h, mode, sclv, window=None, seg_chunks=2):
+def compress(cs, S, h, mode, sclv, window=None, seg_chunks=0):
     """Calibrate + encode every channel of a ChannelSet on the GPU and bring the dense stream to
-    the host as a `Compressed`."""
+    the host as a `Compressed`.  seg_chunks = 0: the planner's choice; the header records it."""
     import torch
 
     from . import WIN_AFTER_CAL, codec
@@ -121,7 +121,7 @@ def compress(cs, S, h, mode, sclv, window=None, seg_chunks=2):
     dense, tot = plan.compact(enc)
     torch.cuda.synchronize()
     total = int(tot.item())
-    c = Compressed(make_header(S, h, mode, window, seg_chunks, sclv), cs.ch_len.copy(),
+    c = Compressed(make_header(S, h, mode, window, plan.seg_chunks, sclv), cs.ch_len.copy(),
                    enc.peak.cpu().numpy(), enc.enc.cpu().numpy(), enc.skipped.cpu().numpy(),
                    enc.ch_bits.cpu().numpy().astype(np.uint64),
                    enc.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments],
@@ -156,69 +156,47 @@ def window_lengths(ch_len, h, window):
 
 
 def validate(c):
-    """Structural check of a container before it goes to the GPU (mh_decode trusts its input: a
-    corrupt chunk header would send the kernel's reads outside the payload).  Walks the chunk
-    headers of every segment on the host -- vectorised over segments -- and verifies that the
-    chunk sizes they imply add up exactly to the directory's word counts, that lengths are
-    possible for the code (<= 256 * max code length) and that per-channel metadata is in range.
-    Raises ValueError."""
-    from . import CHUNK
+    """Structural check of a container before it goes to the GPU.  The header fields are range-
+    checked here; the walk over every chunk header of every segment -- header sizes, sub-stream
+    lengths possible for the channel's code, chunk sizes adding up exactly to the directory and the
+    payload -- is mh_validate_stream (host-only C, no GPU needed).  mh_decode itself never reads
+    outside the payload it is given, so this check is about detecting corruption, not about
+    memory safety.  Raises ValueError."""
+    import ctypes as ct
+
+    from . import _lib
     hd = c.header
-    S, K = int(hd["S"]), int(hd["K"])
-    sclv = np.array(hd["sclv"], np.int64).reshape(K, S)
-    if not (2 <= S <= 10) or sclv.min() < 1 or sclv.max() > 9:
-        raise ValueError("container header: S / code lengths out of range")
+    try:
+        S, K, h, window, seg_chunks, mode = (int(hd[k]) for k in ("S", "K", "h", "window", "seg_chunks", "mode"))
+        sclv = np.ascontiguousarray(np.array(hd["sclv"], np.int64).reshape(K, S))
+    except (KeyError, TypeError, ValueError) as e:
+        raise ValueError("container header: %r" % (e,))
+    if (hd.get("piece"), hd.get("lanes"), hd.get("rows")) != (_lib.PIECE, _lib.LANES, _lib.ROWS):
+        raise ValueError("container header: chunk geometry differs from this library's")
+    if not (2 <= S <= 10) or not (1 <= K <= 255) or sclv.min() < 1 or sclv.max() > 9:
+        raise ValueError("container header: S / K / code lengths out of range")
+    if not (0 <= h <= 30) or not (0 <= window <= 3) or not (0 <= mode <= 1) or not (1 <= seg_chunks <= 1 << 20):
+        raise ValueError("container header: h / window / mode / seg_chunks out of range")
     C = len(c.ch_len)
     if not (len(c.peak) == len(c.enc) == len(c.skipped) == len(c.ch_bits) == C):
         raise ValueError("container arrays disagree about the channel count")
-    if C and (int(c.enc.max()) >= K or int(c.peak.max()) >= S):
-        raise ValueError("per-channel (peak, encoder) word out of range")
-    n_win = window_lengths(c.ch_len, hd["h"], hd["window"])
-    seg = int(hd["seg_chunks"]) * CHUNK
-    nseg_ch = (n_win + seg - 1) // seg
-    nseg = int(nseg_ch.sum())
-    if nseg != len(c.seg_words):
-        raise ValueError("container directory does not match its header")
-    if int(c.seg_words.sum()) != c.payload.size:
-        raise ValueError("payload size does not match the directory")
-    if nseg == 0:
+    if C == 0:
+        if len(c.seg_words) or c.payload.size:
+            raise ValueError("container directory does not match its header")
         return
-    seg_ch = np.repeat(np.arange(C), nseg_ch)
-    first = np.concatenate([[0], np.cumsum(nseg_ch)])[:-1]
-    k_in_ch = np.arange(nseg) - np.repeat(first, nseg_ch)               # segment index inside its channel
-    seg_n = np.minimum(n_win[seg_ch] - k_in_ch * seg, seg)             # samples per segment
-    maxlen = sclv[c.enc[seg_ch].astype(np.int64)].max(axis=1)          # longest code of the channel's encoder
-    start = np.concatenate([[0], np.cumsum(c.seg_words.astype(np.int64))])
-    pos, end = start[:-1].copy(), start[1:]
-    pay = np.concatenate([c.payload, np.zeros(32, np.uint32)]).astype(np.uint64)
-    lanes = np.arange(64, dtype=np.int64)
-    left = seg_n.copy()
-    for _ in range(int(hd["seg_chunks"])):
-        act = np.nonzero(left > 0)[0]
-        if act.size == 0:
-            break
-        p = pos[act]
-        if np.any(p >= end[act]):
-            raise ValueError("segment shorter than its chunk headers say")
-        w0 = pay[p]
-        mn, w = (w0 & 0xFFF).astype(np.int64), ((w0 >> 12) & 15).astype(np.int64)
-        if np.any(w > 12):
-            raise ValueError("chunk header: field width above 12")
-        hw = (16 + 64 * w + 31) >> 5
-        fb = 16 + lanes[None, :] * w[:, None]                           # [segments, 64] field bit positions
-        wi = p[:, None] + (fb >> 5)
-        v = pay[wi] | (pay[wi + 1] << np.uint64(32))
-        f = ((v >> (fb & 31).astype(np.uint64)) & ((np.uint64(1) << w[:, None].astype(np.uint64)) - np.uint64(1))).astype(np.int64)
-        lens = mn[:, None] + f
-        m = np.minimum(left[act], CHUNK)
-        if np.any(lens.max(axis=1) > 256 * maxlen[act]) or np.any(lens.sum(axis=1) > m * maxlen[act]):
-            raise ValueError("chunk header: sub-stream lengths impossible for this code")
-        if np.any(lens.sum(axis=1) < m):                                # every codeword has >= 1 bit
-            raise ValueError("chunk header: fewer bits than samples")
-        pos[act] = p + hw + ((lens.sum(axis=1) + 31) >> 5)
-        left[act] -= m
-    if np.any(left > 0) or np.any(pos != end):
-        raise ValueError("chunk sizes do not add up to the directory's segment sizes")
+    if int(c.ch_len.min()) == 0:
+        raise ValueError("container holds an empty channel")
+    ch_len = np.ascontiguousarray(c.ch_len, np.uint64)
+    rows = np.ascontiguousarray(sclv, np.uint8)
+    pay = np.ascontiguousarray(c.payload, np.uint32)
+    segw = np.ascontiguousarray(c.seg_words, np.uint64)
+    peak, enc = np.ascontiguousarray(c.peak, np.uint8), np.ascontiguousarray(c.enc, np.uint8)
+    rc = _lib.lib().mh_validate_stream(ch_len.ctypes.data, C, S, h, mode, window, rows.ctypes.data, K, seg_chunks,
+                                       pay.ctypes.data if pay.size else np.zeros(1, np.uint32).ctypes.data, pay.size,
+                                       segw.ctypes.data if segw.size else np.zeros(1, np.uint64).ctypes.data, segw.size,
+                                       peak.ctypes.data, enc.ctypes.data)
+    if rc != 0:
+        raise ValueError("corrupt container: " + _lib.lib().mh_last_error().decode(errors="replace"))
 
 
 def decompress(c, device="cuda", channels=None, check=True):
@@ -266,6 +244,8 @@ def decompress(c, device="cuda", channels=None, check=True):
                       torch.from_numpy(np.ascontiguousarray(enc)).to(dev), torch.from_numpy(np.ascontiguousarray(skipped)).to(dev),
                       torch.from_numpy(seg_off).to(dev), True)
     plan.decode(e, cs.data)
-    torch.cuda.synchronize()
+    ok = plan.decode_ok()  # synchronises
     plan.close()
+    if not ok:
+        raise ValueError("corrupt container: a chunk header points outside the payload (decode abandoned)")
     return cs

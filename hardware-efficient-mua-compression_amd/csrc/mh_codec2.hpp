@@ -456,37 +456,16 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
     return make_uint4(words, bits, pend, (uint32_t)(dst - dst0));
 }
 
-template <int LC, int PB, int ABL = 0>
-__global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
+// One segment, one wave: the chunks of segment `seg` of channel `ch` through the wave's tables
+// (lut2 pair table, lut1 single-symbol table) and its staging buffer.
+template <int LC, int PB, int ABL>
+__device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, uint32_t ch, const uint2 *lut2,
+                                               const uint2 *lut1, uint32_t *buf, uint32_t cap, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t task = blockIdx.x;
-    const uint32_t seg0 = a.t.task_seg0[task];
-    const uint32_t nseg = a.t.task_n[task];
-    const uint32_t ch = a.e.seg_ch[seg0];
-    uint2 *lut2 = reinterpret_cast<uint2 *>(smem);
-    uint2 *lut1 = reinterpret_cast<uint2 *>(smem + 512);
-    {   // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
-        const uint2 *g = a.e.lut + (size_t)ch * kLut;
-        const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
-        if (threadIdx.x < (1u << (2 * PB))) {
-            const uint2 ea = g[b0], eb = g[b1];
-            uint32_t idx = b0 | (b1 << PB);
-            if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
-            lut2[idx] = make_uint2(ea.x | (eb.x << ea.y), ea.y + eb.y);
-        }
-        if (threadIdx.x < kLut) lut1[threadIdx.x] = g[threadIdx.x];
-    }
-    __syncthreads();
-    if ((uint32_t)wave >= nseg) return;
-    const uint32_t seg = seg0 + wave;
-    const uint32_t cap = a.e.stage_dw;
-    uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
-    const uint8_t *src = a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg];
-    const uint64_t n = a.e.seg_n[seg];
-    uint32_t *__restrict__ out = a.e.payload + a.e.seg_off[seg];  // next unflushed word
-    uint32_t pend = 0;                                            // words waiting in LDS behind `out`
+    const uint8_t *src = e.data + e.ch_off[ch] + e.w0[ch] + e.seg_first[seg];
+    const uint64_t n = e.seg_n[seg];
+    uint32_t *__restrict__ out = e.payload + e.seg_off[seg];  // next unflushed word
+    uint32_t pend = 0;                                        // words waiting in LDS behind `out`
     const uint32_t nfull = (uint32_t)(n / kChunk);
     const uint32_t rem = (uint32_t)(n % kChunk);
     uint64_t words = 0, bits = 0;
@@ -512,9 +491,77 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     }
     if (ABL < 1 && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
     if (lane == 0) {
-        a.e.seg_words[seg] = words;
-        atomicAdd(&a.e.ch_bits[ch], (unsigned long long)bits);
+        e.seg_words[seg] = words;
+        atomicAdd(&e.ch_bits[ch], (unsigned long long)bits);
     }
+}
+
+// Long channels: a workgroup owns up to 4 consecutive segments OF ONE CHANNEL and shares its tables.
+template <int LC, int PB, int ABL = 0>
+__global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x;
+    const uint32_t seg0 = a.t.task_seg0[task];
+    const uint32_t nseg = a.t.task_n[task];
+    const uint32_t ch = a.e.seg_ch[seg0];
+    uint2 *lut2 = reinterpret_cast<uint2 *>(smem);
+    uint2 *lut1 = reinterpret_cast<uint2 *>(smem + 512);
+    {   // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
+        const uint2 *g = a.e.lut + (size_t)ch * kLut;
+        const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
+        if (threadIdx.x < (1u << (2 * PB))) {
+            const uint2 ea = g[b0], eb = g[b1];
+            uint32_t idx = b0 | (b1 << PB);
+            if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
+            lut2[idx] = make_uint2(ea.x | (eb.x << ea.y), ea.y + eb.y);
+        }
+        if (threadIdx.x < kLut) lut1[threadIdx.x] = g[threadIdx.x];
+    }
+    __syncthreads();
+    if ((uint32_t)wave >= nseg) return;
+    const uint32_t cap = a.e.stage_dw;
+    uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
+    encode_segment<LC, PB, ABL>(a.e, seg0 + wave, ch, lut2, lut1, buf, cap, lane);
+}
+
+// Short channels (the reference's real recordings at 50 ms bins are 2e4-7e4 samples per channel,
+// Data/get_all_binned_data.py:16): one WAVE per segment, any channel, with the wave's own tables,
+// so a workgroup packs segments of four different channels and no wave idles.  task_seg0[i] is the
+// segment of wave-task i (the planner orders them longest first).
+__host__ __device__ inline uint32_t enc2w_wave_dwords(uint32_t stage_dw) { return kEncSharedDw + enc2_wave_dwords(stage_dw); }
+
+template <int LC, int PB>
+__global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * 4 + (uint32_t)wave;
+    if (slot >= a.t.ntask) return;
+    const uint32_t seg = a.t.task_seg0[slot];
+    const uint32_t ch = a.e.seg_ch[seg];
+    const uint32_t cap = a.e.stage_dw;
+    uint32_t *wbase = smem + (size_t)wave * enc2w_wave_dwords(cap);
+    uint2 *lut2 = reinterpret_cast<uint2 *>(wbase);
+    uint2 *lut1 = reinterpret_cast<uint2 *>(wbase + 512);
+    {
+        const uint2 *g = a.e.lut + (size_t)ch * kLut;
+        const uint2 el = lane < kLut ? g[lane] : make_uint2(0u, 0u);  // the 16 single-symbol entries, one per lane
+        constexpr uint32_t m = (1u << PB) - 1u;
+#pragma unroll
+        for (uint32_t t0 = 0; t0 < (1u << (2 * PB)); t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane, b0 = t & m, b1 = (t >> PB) & m;
+            const uint32_t ax = __shfl(el.x, (int)b0, 64), ay = __shfl(el.y, (int)b0, 64);
+            const uint32_t bx = __shfl(el.x, (int)b1, 64), by = __shfl(el.y, (int)b1, 64);
+            uint32_t idx = b0 | (b1 << PB);
+            if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
+            lut2[idx] = make_uint2(ax | (bx << ay), ay + by);
+        }
+        if (lane < kLut) lut1[lane] = el;
+    }
+    MH_WAVE_SYNC();
+    encode_segment<LC, PB, 0>(a.e, seg, ch, lut2, lut1, wbase + kEncSharedDw, cap, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -524,9 +571,11 @@ struct Dtab2Args {
     const uint8_t *peak, *enc, *sclv;
     const uint32_t *codes;
     uint32_t C, S, mode, W, K;
+    uint32_t nK;  // encoders in the plan
     void *dtab2;  // K == 4 plans only: C << W entries uint2 {4 symbol bytes, bits consumed}
     uint8_t *dtab;  // C*512 per-symbol table: symbol | len << 4, indexed by the next maxlen bits
     uint8_t *dlen;  // C : max code length of the channel's encoder
+    uint32_t *err;  // decode status word, cleared here (this kernel precedes every decode launch)
 };
 
 // Per-symbol table of every channel, and for K == 4 plans (maxlen <= 2) the 4-symbol table:
@@ -536,8 +585,10 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
 {
     const uint32_t ch = blockIdx.x;
     const int S = (int)a.S, W = (int)a.W, K = (int)a.K;
-    const int p = a.peak[ch];
-    const uint32_t k = a.enc[ch];
+    if (ch == 0 && threadIdx.x == 0) *a.err = 0;
+    // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
+    const int p = a.peak[ch] < S ? a.peak[ch] : 0;
+    const uint32_t k = a.enc[ch] < a.nK ? a.enc[ch] : 0;
     __shared__ uint32_t code[16], clen[16], sym[16];
     if (threadIdx.x < (uint32_t)S) {
         const uint32_t c = a.codes[k * 16 + threadIdx.x];
@@ -617,7 +668,7 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw32, int lane)
 // lanes whose piece is not complete skip the row, and the one cut piece (m % 16 samples) is decoded
 // symbol by symbol from the same window.
 template <int K, int M, int RL, bool HY, bool PARTIAL = false>
-__device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *tabw, uint32_t maskW,
+__device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *tabw, uint32_t tbase, uint32_t maskW,
                                                     const uint8_t *tab1, uint32_t mask1,
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
                                                     int lane, uint32_t m = kChunk)
@@ -638,7 +689,8 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
     // Pre-scaled index: the window is kept SH bits "early" (bp = stream position - SH, counted
     //   from the word before the staged payload), so (window >> bp) & (mask << SH) is already the
     //   byte offset of the table entry -- no shift in the lookup's dependent chain.  The table
-    //   sits at LDS address 0, so the offset is the address.  Pair tables only: with K = 4 the
+    //   sits at LDS byte address `tbase` (0 in the shared-table kernel, where the offset IS the
+    //   address; the per-wave-table kernel pays one add).  Pair tables only: with K = 4 the
     //   last of the 4 lookups between reloads may start at window bit 55 and needs 8 more, which
     //   leaves no room for scale bits.
     constexpr bool kReload = RL == 1;
@@ -688,7 +740,7 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
                     w = e.x;
                     adv = e.y;
                 } else {
-                    const uint32_t e = *reinterpret_cast<lds_u1 *>(off);
+                    const uint32_t e = *reinterpret_cast<lds_u1 *>(off + tbase);
                     w |= (e & 0xFFFFu) << (8 * K * i);
                     adv = HY ? (e >> 16) & 0x7FFFu : e >> 16;
                     if (HY && (int32_t)e < 0) {  // rare: second codeword reaches past the index bits
@@ -746,12 +798,16 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
 // routine on global memory.
 template <int K, int M, int RL, bool HY>
 __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict__ in, uint32_t m, const uint32_t *tabw,
-                                                  uint32_t maskW, const uint8_t *tab1, uint32_t mask1,
+                                                  uint32_t tbase, uint32_t maskW, const uint8_t *tab1, uint32_t mask1,
                                                   uint32_t *stage, uint32_t cap_words, uint8_t *__restrict__ out,
-                                                  int lane)
+                                                  int lane, uint64_t avail, uint32_t *err)
 {
+    // avail = words readable from `in` on; the chunk's header, payload and 3 words of read-ahead
+    // must lie inside, else the chunk is abandoned (corrupt or truncated stream)
+    if (avail < 1) { if (lane == 0) atomicOr(err, 1u); return; }
     const uint32_t w0 = in[0];
     const uint32_t mn = w0 & 0xFFFu, hwid = (w0 >> 12) & 15u;
+    if (avail < hdr_words(hwid)) { if (lane == 0) atomicOr(err, 1u); return; }
     uint32_t len = mn;
     if (hwid) {
         const uint32_t fb = 16u + (uint32_t)lane * hwid;
@@ -765,6 +821,7 @@ __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict_
     h.nw = (__shfl(incl, 63, 64) + 31) >> 5;
     h.hw = hdr_words(hwid);
     const uint32_t ns = h.nw + 3;
+    if (avail < (uint64_t)h.hw + ns) { if (lane == 0) atomicOr(err, 1u); return; }
     if (ns > cap_words) {
         decode_chunk<3, false>(in, m, tab1, mask1, out, lane);
         return;
@@ -783,7 +840,87 @@ __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict_
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    decode_staged_chunk<K, M, RL, HY, true>(h, tabw, maskW, tab1, mask1, stage, out, lane, m);
+    decode_staged_chunk<K, M, RL, HY, true>(h, tabw, tbase, maskW, tab1, mask1, stage, out, lane, m);
+}
+
+// One segment, one wave: the chunks of segment `seg` through the wave's tables (`tab` multi-symbol
+// table at LDS byte address `tbase`, `tab1` per-symbol table) and its payload staging area.
+template <int K, int M, int NR, int RL, bool HY>
+__device__ __forceinline__ void decode_segment(const DecArgs &d, uint32_t seg, uint32_t ch, const uint32_t *tab,
+                                               uint32_t tbase, uint32_t maskW, const uint8_t *tab1, uint32_t mask1,
+                                               uint32_t *stage, int lane)
+{
+    constexpr uint32_t kCap = NR * 64;
+    // Untrusted input: `pos` = word index of the chunk being entered, `lim` = words that may be
+    // read.  Before any read that a header value steers, the wave checks (wave-uniform, a few
+    // scalar operations per chunk) that header + payload + 3 words of read-ahead (+ the next
+    // chunk's first 32 words where there is one) lie below lim; otherwise the segment is abandoned
+    // and *err set.  Stores only ever go to the plan's own window positions.
+    const uint64_t lim = d.payload_words;
+    uint64_t pos = d.seg_off[seg];
+    const uint32_t *in = d.payload + pos;
+    uint8_t *out = d.out + d.ch_off[ch] + d.w0[ch] + d.seg_first[seg];
+    const uint64_t n = d.seg_n[seg];
+    const uint32_t nfull = (uint32_t)(n / kChunk);
+    const uint32_t rem = (uint32_t)(n % kChunk);
+#define MH_DEC_BAIL()                              \
+    do {                                           \
+        if (lane == 0) atomicOr(d.err, 1u);        \
+        return;                                    \
+    } while (0)
+    if (nfull) {
+        uint32_t R[NR];
+        if (pos + 32 > lim) MH_DEC_BAIL();
+        ChunkHdr cur = scan_header(in[lane & 31], lane);
+        if (pos + cur.hw + cur.nw + 3 + (nfull > 1 ? 32 : 0) > lim) MH_DEC_BAIL();
+        const uint32_t *pay = in + cur.hw;
+        uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            if ((uint32_t)(j * 64) < ns) {  // wave-uniform; the index clamp keeps the last row inside nw + 2
+                const uint32_t i_ = (uint32_t)(j * 64 + lane);
+                R[j] = pay[i_ < ns ? i_ : ns - 1];
+            }
+        uint32_t hw_next = 0;
+        if (nfull > 1) hw_next = pay[cur.nw + (lane & 31)];
+        for (uint32_t c = 0; c < nfull; ++c) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j)  // payload(c): registers -> LDS
+                if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
+            const ChunkHdr hc = cur;
+            const uint32_t *chunk_c = pay - cur.hw;  // first header word of chunk c
+            const bool staged = ns != 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
+                const uint32_t *nextc = pay + cur.nw;  // chunk c+1
+                pos += cur.hw + cur.nw;
+                cur = scan_header(hw_next, lane);
+                if (pos + cur.hw + cur.nw + 3 + (c + 2 < nfull ? 32 : 0) > lim) MH_DEC_BAIL();
+                pay = nextc + cur.hw;
+                ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    if ((uint32_t)(j * 64) < ns) {
+                        const uint32_t i_ = (uint32_t)(j * 64 + lane);
+                        R[j] = pay[i_ < ns ? i_ : ns - 1];
+                    }
+                if (c + 2 < nfull) hw_next = pay[cur.nw + (lane & 31)];
+            }
+            if (staged)
+                decode_staged_chunk<K, M, RL, HY>(hc, tab, tbase, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
+            else
+                decode_chunk<3, true>(chunk_c, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        in = pay + cur.nw;  // first word after the last full chunk
+        pos += cur.hw + cur.nw;
+    }
+    if (rem)
+        decode_partial_chunk<K, M, RL, HY>(in, rem, tab, tbase, maskW, tab1, mask1, stage, kCap, out + (size_t)nfull * kChunk,
+                                            lane, pos < lim ? lim - pos : 0, d.err);
+#undef MH_DEC_BAIL
 }
 
 // NR payload registers per lane: the next chunk's payload (up to NR*64 words) is fetched into
@@ -795,6 +932,8 @@ __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict_
 #ifndef MH_DEC_MIN_WAVES
 #define MH_DEC_MIN_WAVES 1
 #endif
+// Long channels: up to 4 consecutive segments of ONE channel per workgroup, tables shared at LDS
+// address 0 (the kernel has no static LDS; mh_plan_create verifies that from the code object).
 template <int K, int M, int NR, int RL, bool HY>
 __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
 {
@@ -807,8 +946,6 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
     const uint32_t W = a.W;
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
     uint32_t *tab = smem;
-    // the lookups address the table by raw LDS offset (see decode_staged_chunk)
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)smem != 0u) __builtin_trap();
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (kEntDw << W));
     const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
     if (threadIdx.x < kDtab / 8)
@@ -833,60 +970,52 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
     }
     __syncthreads();
     if ((uint32_t)wave >= nseg) return;
-    const uint32_t seg = seg0 + wave;
-    constexpr uint32_t kCap = NR * 64;
-    uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * kCap;
-    const uint32_t maskW = (1u << W) - 1u;
-    const uint32_t *in = a.d.payload + a.d.seg_off[seg];
-    uint8_t *out = a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg];
-    const uint64_t n = a.d.seg_n[seg];
-    const uint32_t nfull = (uint32_t)(n / kChunk);
-    const uint32_t rem = (uint32_t)(n % kChunk);
-    if (nfull) {
-        uint32_t R[NR];
-        ChunkHdr cur = scan_header(in[lane & 31], lane);
-        const uint32_t *pay = in + cur.hw;
-        uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
-#pragma unroll
-        for (int j = 0; j < NR; ++j)
-            if ((uint32_t)(j * 64) < ns) {  // wave-uniform; the index clamp keeps the last row inside nw + 2
-                const uint32_t i_ = (uint32_t)(j * 64 + lane);
-                R[j] = pay[i_ < ns ? i_ : ns - 1];
-            }
-        uint32_t hw_next = 0;
-        if (nfull > 1) hw_next = pay[cur.nw + (lane & 31)];
-        for (uint32_t c = 0; c < nfull; ++c) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j)  // payload(c): registers -> LDS
-                if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
-            const ChunkHdr hc = cur;
-            const uint32_t *chunk_c = pay - cur.hw;  // first header word of chunk c
-            const bool staged = ns != 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
-                const uint32_t *nextc = pay + cur.nw;  // chunk c+1
-                cur = scan_header(hw_next, lane);
-                pay = nextc + cur.hw;
-                ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
-#pragma unroll
-                for (int j = 0; j < NR; ++j)
-                    if ((uint32_t)(j * 64) < ns) {
-                        const uint32_t i_ = (uint32_t)(j * 64 + lane);
-                        R[j] = pay[i_ < ns ? i_ : ns - 1];
-                    }
-                if (c + 2 < nfull) hw_next = pay[cur.nw + (lane & 31)];
-            }
-            if (staged)
-                decode_staged_chunk<K, M, RL, HY>(hc, tab, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
-            else
-                decode_chunk<3, true>(chunk_c, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        in = pay + cur.nw;  // first word after the last full chunk
+    uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * (NR * 64);
+    decode_segment<K, M, NR, RL, HY>(a.d, seg0 + wave, ch, tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
+}
+
+// Short channels: one WAVE per segment of any channel, tables per wave (see k_encode2w).
+template <int K, int M, int NR, int RL, bool HY>
+__global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * 4 + (uint32_t)wave;
+    if (slot >= a.t.ntask) return;
+    const uint32_t seg = a.t.task_seg0[slot];
+    const uint32_t ch = a.d.seg_ch[seg];
+    const uint32_t W = a.W;
+    constexpr uint32_t kEntDw = K == 4 ? 2 : 1;
+    const uint32_t wdw = dec2_shared_dwords(W, K) + NR * 64;  // dwords per wave
+    uint32_t *tab = smem + (size_t)wave * wdw;
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (kEntDw << W));
+    const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
+    {
+        const uint32_t *g1 = reinterpret_cast<const uint32_t *>(a.d.dtab + (size_t)ch * kDtab);
+        uint32_t *t1 = reinterpret_cast<uint32_t *>(tab1);
+        t1[lane] = g1[lane];
+        t1[lane + 64] = g1[lane + 64];
     }
-    if (rem) decode_partial_chunk<K, M, RL, HY>(in, rem, tab, maskW, tab1, mask1, stage, kCap, out + (size_t)nfull * kChunk, lane);
+    if (K == 4) {
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(a.dtab2) + (((size_t)ch << W) * kEntDw);
+        for (uint32_t i = lane; i < (kEntDw << W); i += 64) tab[i] = g[i];
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t idx = lane; idx < (1u << W); idx += 64) {
+            const uint32_t e1 = tab1[idx & mask1];
+            const uint32_t l1 = e1 >> 4;
+            const uint32_t e2 = tab1[(idx >> l1) & mask1];
+            const uint32_t l2 = e2 >> 4;
+            tab[idx] = l1 + l2 <= W ? (e1 & 15u) | ((e2 & 15u) << 8) | ((l1 + l2) << 16)
+                                    : (e1 & 15u) | (l1 << 16) | 0x80000000u;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tab;
+    decode_segment<K, M, NR, RL, HY>(a.d, seg, ch, tab, tbase, (1u << W) - 1u, tab1, mask1,
+                                     tab + dec2_shared_dwords(W, K), lane);
 }
 
 // ------------------------------------------------------------------------------------------

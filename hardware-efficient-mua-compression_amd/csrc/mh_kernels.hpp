@@ -302,6 +302,10 @@ struct DecArgs {
     const uint8_t *dtab, *dlen;
     uint8_t *out;
     uint32_t nseg;
+    // every read of the stream stays below payload + payload_words whatever the stream holds; a
+    // segment whose headers point outside is abandoned and *err is set
+    uint64_t payload_words;
+    uint32_t *err;
 };
 
 template <int FI, bool FULL>
@@ -324,7 +328,9 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in
     const uint32_t B = __shfl(incl, 63, 64);
     const uint32_t *pay = in + hw;
     uint32_t wi = P >> 5, bp = P & 31;
-    // 64-bit window + one word of read-ahead; reads may run <= 3 words past the chunk
+    // 64-bit window + one word of read-ahead; reads run <= 3 words past the chunk's own words even
+    // when a corrupt stream decodes to more bits than its header announces (index clamp below)
+    const uint32_t nw = (B + 31) >> 5;
     uint64_t buf = (uint64_t)pay[wi] | ((uint64_t)pay[wi + 1] << 32);
     uint32_t nxt = pay[wi + 2];
 #pragma unroll
@@ -349,7 +355,7 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in
                     buf = (buf >> 32) | ((uint64_t)nxt << 32);
                     bp -= 32;
                     ++wi;
-                    nxt = pay[wi + 2];
+                    nxt = pay[(wi < nw ? wi : nw) + 2];
                 }
             }
         }
@@ -361,7 +367,7 @@ __device__ __forceinline__ uint32_t decode_chunk(const uint32_t *__restrict__ in
                 if (i < cnt) out[base + i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
         }
     }
-    return hw + ((B + 31) >> 5);
+    return hw + nw;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,247 @@
+// mh_planner.hpp -- the host-side planner of libmuahuff: windows, segment directory, slots,
+// workgroup tasks, histogram tiles, codebooks, decoder geometry.  Pure C++ (no HIP, no device):
+// muahuff.hip uploads what it computes; tests/planner_check.cpp compiles the same header with
+// -fsanitize=address,undefined and checks it against the CPU oracle's directory.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "muahuff.h"
+
+namespace mh {
+
+constexpr uint32_t kHistTileBytes = 256 * 16 * 32;  // bytes of one histogram tile (128 KiB)
+constexpr uint64_t kCalDirect = 4096;                // longest calibration window k_calibrate scans itself
+constexpr uint64_t kAutoSegLimit = 16384;            // seg_chunks = 0: one-chunk segments below this many two-chunk ones
+
+inline uint32_t bitrev(uint32_t v, int n)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
+    return r;
+}
+
+// A row is a sorted codeword-length vector of a complete prefix code (Kraft sum exactly 1,
+// Compressing data/Produce SCLVs/produce_all_SCLVs_given_S.py:87-98), lengths 1..9.
+inline int check_sclv_row(const uint8_t *row, int S, uint32_t *maxlen)
+{
+    uint32_t m = 0;
+    for (int r = 0; r < S; ++r) {
+        if (row[r] == 0 || row[r] > 9) return MH_ERR_SCLV;
+        if (r && row[r] < row[r - 1]) return MH_ERR_SCLV;
+        if (row[r] > m) m = row[r];
+    }
+    uint32_t kraft = 0;
+    for (int r = 0; r < S; ++r) kraft += 1u << (m - row[r]);
+    if (kraft != (1u << m)) return MH_ERR_SCLV;
+    *maxlen = m;
+    return MH_OK;
+}
+
+// canonical codewords, MSB-first values, rank 0 shortest ([1,2,2] -> 0,10,11 == test_chosen_system.py:26)
+inline void canonical_codes(const uint8_t *row, int S, uint16_t *code, uint8_t *len)
+{
+    uint32_t c = 0;
+    for (int r = 0; r < S; ++r) {
+        if (r) c = (c + 1) << (row[r] - row[r - 1]);
+        code[r] = (uint16_t)c;
+        len[r] = row[r];
+    }
+}
+
+// words a segment of n samples may need at most (what slots are sized by): every chunk a full
+// 32-word header bound plus maxlen bits per sample, rounded up to a 128-byte line
+inline uint64_t slot_words(uint64_t n, uint32_t maxlen)
+{
+    const uint64_t full = n / MH_CHUNK, rem = n % MH_CHUNK;
+    uint64_t words = (full + (rem ? 1 : 0)) * MH_HDR_WORDS + full * (((uint64_t)MH_CHUNK * maxlen + 31) / 32);
+    if (rem) words += (rem * maxlen + 31) / 32;
+    return (words + 31) & ~(uint64_t)31;
+}
+
+struct PlanHost {
+    mh_plan_info_t info{};
+    uint64_t max_T = 0;
+    std::vector<uint64_t> ch_off, ch_len, w0, w1;
+    std::vector<uint8_t> skip, sclv;
+    std::vector<uint32_t> codes;  // K*16: bit-reversed code | len << 16, by rank
+    // segment directory
+    std::vector<uint32_t> seg_ch;
+    std::vector<uint64_t> seg_first, seg_n, seg_off;
+    // workgroup tasks of the shared-table kernels: <= 4 consecutive segments of one channel
+    std::vector<uint32_t> task_seg0;
+    std::vector<uint8_t> task_n;
+    // wave tasks of the per-wave-table kernels: every segment once, longest first
+    std::vector<uint32_t> wave_seg;
+    bool use_wave_tasks = false;
+    // window-histogram tiles, calibration tiles (windows above kCalDirect samples)
+    std::vector<uint32_t> tile_ch, tile_n, cal_tile_ch, cal_tile_n;
+    std::vector<uint64_t> tile_start, cal_tile_start;
+    // decoder geometry
+    uint32_t W = 0, dec_K = 4, dec_NR = 32;
+};
+
+struct PlanTuning {  // MH_TUNING builds only; the defaults are the measured best (profiles/README.md)
+    int dec_w_cap = 10;   // index bits of the hybrid pair table
+    int dec_nr = 31;      // staging registers per lane of the hybrid decoder
+    int wave_tasks = -1;  // -1 = planner's rule, 0 / 1 = force
+};
+
+// windows of one channel: c = min(2^h, T) (functions_1.py:59-64), e = c + T/2 (get_BR_with_approx_sort.py:180)
+inline void channel_window(uint64_t T, uint32_t h, uint32_t window, uint64_t *w0, uint64_t *w1, uint8_t *skip)
+{
+    const uint64_t lim = (uint64_t)1 << h;
+    const uint64_t cut = T < lim ? T : lim, e = cut + T / 2;
+    *skip = 0;
+    switch (window) {
+    case MH_WIN_REF_HALF:
+        if (e > T) {  // :183-185 skipped, shows up as NaN in the reference
+            *skip = 1;
+            *w0 = *w1 = cut;
+        } else {
+            *w0 = cut;
+            *w1 = e;
+        }
+        break;
+    case MH_WIN_REF_HALF_TRUNC: *w0 = cut; *w1 = e > T ? T : e; break;
+    case MH_WIN_AFTER_CAL: *w0 = cut; *w1 = T; break;
+    default: *w0 = 0; *w1 = T; break;
+    }
+}
+
+// Argument checks shared by mh_plan_create and mh_plan_query; returns MH_OK or the error code and
+// a message (static strings with at most one %u).
+inline int plan_check_args(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h, uint32_t mode, uint32_t window,
+                           const uint8_t *sclv, uint32_t K, uint32_t *maxlen_out, const char **msg, uint32_t *msg_arg)
+{
+    *msg_arg = 0;
+    if (C == 0) { *msg = "C == 0"; return MH_ERR_ARG; }
+    if (S < 2 || S > 10) { *msg = "S=%u outside 2..10"; *msg_arg = S; return MH_ERR_ARG; }
+    if (h > 30) { *msg = "h=%u outside 0..30"; *msg_arg = h; return MH_ERR_ARG; }
+    if (mode > MH_MODE_APPROX) { *msg = "mode=%u unknown"; *msg_arg = mode; return MH_ERR_ARG; }
+    if (window > MH_WIN_FULL) { *msg = "window=%u unknown"; *msg_arg = window; return MH_ERR_ARG; }
+    if (K == 0 || K > 255) { *msg = "K=%u outside 1..255"; *msg_arg = K; return MH_ERR_ARG; }
+    uint32_t maxlen = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        uint32_t m;
+        if (check_sclv_row(sclv + (size_t)k * S, (int)S, &m) != MH_OK) {
+            *msg = "SCLV row %u is not a non-decreasing complete code-length vector";
+            *msg_arg = k;
+            return MH_ERR_SCLV;
+        }
+        if (m > maxlen) maxlen = m;
+    }
+    for (uint32_t c = 0; c < C; ++c)
+        if (ch_len[c] == 0) {
+            *msg = "channel %u has no bins (the reference raises IndexError)";
+            *msg_arg = c;
+            return MH_ERR_EMPTY_CHANNEL;
+        }
+    *maxlen_out = maxlen;
+    return MH_OK;
+}
+
+// Everything mh_plan_create uploads, computed on the host.  `info` must hold C, S, h, mode, window,
+// K, seg_chunks (0 = choose) and maxlen; arguments are already checked.
+inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t *ch_len, const uint8_t *sclv,
+                            const PlanTuning &tune = PlanTuning())
+{
+    mh_plan_info_t &I = p.info;
+    const uint32_t C = I.C, S = I.S, K = I.K;
+    p.ch_off.assign(ch_off, ch_off + C);
+    p.ch_len.assign(ch_len, ch_len + C);
+    p.w0.resize(C);
+    p.w1.resize(C);
+    p.skip.assign(C, 0);
+    uint64_t total = 0, nskip = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+        const uint64_t T = ch_len[c];
+        if (T > p.max_T) p.max_T = T;
+        channel_window(T, I.h, I.window, &p.w0[c], &p.w1[c], &p.skip[c]);
+        nskip += p.skip[c];
+        total += p.w1[c] - p.w0[c];
+    }
+    I.window_samples = total;
+    I.n_skipped = nskip;
+    // segment length: the caller's, or two chunks -- one when that leaves the chip short of work
+    // (short recordings: finer tasks fill the last round of workgroups better)
+    if (I.seg_chunks == 0) {
+        uint64_t nseg2 = 0;
+        for (uint32_t c = 0; c < C; ++c) nseg2 += (p.w1[c] - p.w0[c] + 2 * MH_CHUNK - 1) / (2 * MH_CHUNK);
+        I.seg_chunks = nseg2 < kAutoSegLimit ? 1 : 2;
+    }
+    const uint64_t seg_samples = (uint64_t)I.seg_chunks * MH_CHUNK;
+    uint64_t slot = 0, padded_waves = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+        const uint64_t n = p.w1[c] - p.w0[c];
+        const size_t seg_begin = p.seg_ch.size();
+        for (uint64_t first = 0; first < n; first += seg_samples) {
+            const uint64_t m = n - first < seg_samples ? n - first : seg_samples;
+            p.seg_ch.push_back(c);
+            p.seg_first.push_back(first);
+            p.seg_n.push_back(m);
+            p.seg_off.push_back(slot);
+            slot += slot_words(m, I.maxlen);
+        }
+        for (size_t s0 = seg_begin; s0 < p.seg_ch.size(); s0 += 4) {
+            p.task_seg0.push_back((uint32_t)s0);
+            p.task_n.push_back((uint8_t)(p.seg_ch.size() - s0 < 4 ? p.seg_ch.size() - s0 : 4));
+            padded_waves += 4;
+        }
+        for (uint64_t first = 0; first < n; first += kHistTileBytes) {
+            p.tile_ch.push_back(c);
+            p.tile_start.push_back(p.w0[c] + first);
+            p.tile_n.push_back((uint32_t)(n - first < kHistTileBytes ? n - first : kHistTileBytes));
+        }
+    }
+    I.n_segments = p.seg_ch.size();
+    I.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
+    // per-wave-table kernels when the shared-table tasks would leave more than 1 wave in 16 idle
+    // (channels of a few segments); their wave tasks run longest first
+    p.use_wave_tasks = padded_waves * 15 > (uint64_t)I.n_segments * 16;
+    if (tune.wave_tasks >= 0) p.use_wave_tasks = tune.wave_tasks != 0;
+    if (p.use_wave_tasks) {
+        p.wave_seg.resize(p.seg_ch.size());
+        std::iota(p.wave_seg.begin(), p.wave_seg.end(), 0u);
+        std::stable_sort(p.wave_seg.begin(), p.wave_seg.end(),
+                         [&](uint32_t a, uint32_t b) { return p.seg_n[a] > p.seg_n[b]; });
+    }
+    // calibration: one wave per channel reads the window directly up to kCalDirect samples (the
+    // reference's range is 2^2..2^10); longer windows go through the tiled histogram kernel
+    const uint64_t lim = (uint64_t)1 << I.h;
+    if (lim > kCalDirect)
+        for (uint32_t c = 0; c < C; ++c) {
+            const uint64_t n = ch_len[c] < lim ? ch_len[c] : lim;
+            for (uint64_t first = 0; first < n; first += kHistTileBytes) {
+                p.cal_tile_ch.push_back(c);
+                p.cal_tile_start.push_back(first);
+                p.cal_tile_n.push_back((uint32_t)(n - first < kHistTileBytes ? n - first : kHistTileBytes));
+            }
+        }
+    // decode table: K symbols per lookup, W index bits.  maxlen <= 5: W = K * maxlen (<= 10), every
+    // entry holds K whole codewords; longer codes: hybrid pair table of 10 index bits and 31
+    // staging registers, which keeps 4 workgroups per CU (tables + staging <= 40 KiB of LDS).
+    p.dec_K = I.maxlen <= 2 ? 4 : 2;
+    p.W = p.dec_K * I.maxlen;
+    p.dec_NR = 32;
+    if (p.dec_K == 2) {
+        uint32_t cap = tune.dec_w_cap >= 8 && tune.dec_w_cap <= 12 ? (uint32_t)tune.dec_w_cap : 10u;
+        if (cap < I.maxlen) cap = I.maxlen;  // a flagged entry still holds its first codeword
+        if (p.W > cap) p.W = cap;
+        if (p.W < 2 * I.maxlen) p.dec_NR = tune.dec_nr == 32 ? 32 : 31;
+    }
+    // codebooks by rank: bit-reversed code (first code bit at bit 0) | len << 16
+    p.codes.assign((size_t)K * 16, 0);
+    for (uint32_t k = 0; k < K; ++k) {
+        uint16_t code[16];
+        uint8_t ln[16];
+        canonical_codes(sclv + (size_t)k * S, (int)S, code, ln);
+        for (uint32_t r = 0; r < S; ++r) p.codes[k * 16 + r] = bitrev(code[r], ln[r]) | ((uint32_t)ln[r] << 16);
+    }
+    p.sclv.assign(sclv, sclv + (size_t)K * S);
+}
+
+}  // namespace mh

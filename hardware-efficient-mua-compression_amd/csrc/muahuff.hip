@@ -10,8 +10,10 @@
 #include <new>
 #include <vector>
 
+#include "mh_analysis.hpp"
 #include "mh_codec2.hpp"
 #include "mh_layout.hpp"
+#include "mh_planner.hpp"
 #include "muahuff.h"
 
 namespace {
@@ -35,31 +37,6 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-uint32_t bitrev(uint32_t v, int n)
-{
-    uint32_t r = 0;
-    for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
-    return r;
-}
-
-int check_row(const uint8_t *row, int S, uint32_t *maxlen)
-{
-    uint32_t m = 0;
-    for (int r = 0; r < S; ++r) {
-        if (row[r] == 0 || row[r] > 9) return MH_ERR_SCLV;
-        if (r && row[r] < row[r - 1]) return MH_ERR_SCLV;
-        if (row[r] > m) m = row[r];
-    }
-    uint32_t kraft = 0;
-    for (int r = 0; r < S; ++r) kraft += 1u << (m - row[r]);
-    if (kraft != (1u << m)) return MH_ERR_SCLV;
-    *maxlen = m;
-    return MH_OK;
-}
-
-constexpr uint32_t kHistTile = 256 * 16 * 32;  // bytes of one histogram tile (128 KiB)
-constexpr uint64_t kCalDirect = 4096;          // longest calibration window k_calibrate scans itself
-
 template <typename T>
 int upload(T **dst, const std::vector<T> &src)
 {
@@ -76,15 +53,24 @@ int alloc(T **dst, size_t n)
     return MH_OK;
 }
 
+// Tuning knobs exist only in -DMH_TUNING builds (A/B runs, tools/); the production library reads
+// no environment variable and exports no debug hook.
+mh::PlanTuning plan_tuning()
+{
+    mh::PlanTuning t;
+#ifdef MH_TUNING
+    if (const char *e = getenv("MH_DEC_W")) t.dec_w_cap = atoi(e);
+    if (const char *e = getenv("MH_DEC_NR")) t.dec_nr = atoi(e);
+    if (const char *e = getenv("MH_WAVE_TASKS")) t.wave_tasks = atoi(e);
+#endif
+    return t;
+}
+
 }  // namespace
 
 struct mh_plan {
     int device = 0;
-    mh_plan_info_t info{};
-    uint64_t max_T = 0;
-    std::vector<uint32_t> seg_ch;
-    std::vector<uint64_t> seg_first, seg_n, seg_off;
-    uint64_t n_tiles = 0;
+    mh::PlanHost h;  // everything the planner computed (host copies)
     // device tables
     uint64_t *d_ch_off = nullptr, *d_ch_len = nullptr, *d_w0 = nullptr, *d_w1 = nullptr;
     uint8_t *d_skip = nullptr, *d_sclv = nullptr;
@@ -97,23 +83,22 @@ struct mh_plan {
     unsigned long long *d_hist = nullptr;
     uint8_t *d_peak = nullptr, *d_enc = nullptr, *d_dtab = nullptr, *d_dlen = nullptr;
     uint2 *d_lut = nullptr;
-    // workgroup tasks: up to 4 consecutive segments of one channel
+    // shared-table kernels: workgroup tasks (first segment, count); per-wave-table kernels: the
+    // segment of every wave task
     uint32_t *d_task_seg0 = nullptr;
     uint8_t *d_task_n = nullptr;
-    uint32_t n_tasks = 0;
-    uint32_t W = 0;  // decode table index bits
-    uint32_t dec_K = 4;  // symbols per decode-table lookup
-    uint32_t dec_NR = 32; // staging registers per lane of the hybrid decoder
+    uint32_t *d_wave_seg = nullptr;
     uint64_t *d_scan = nullptr;  // block sums of mh_compact's segment scan
     // calibration windows above kCalDirect samples: tiles for the window-histogram kernel
     uint32_t *d_cal_tile_ch = nullptr, *d_cal_tile_n = nullptr;
     uint64_t *d_cal_tile_start = nullptr;
     unsigned long long *d_calhist = nullptr;
-    uint64_t n_cal_tiles = 0;
     uint2 *d_dtab2 = nullptr;  // 4-symbol decode tables (dec_K == 4 plans only)
+    uint32_t *d_err = nullptr;  // decode status word (mh_decode_status)
 };
 
 struct mh_sweep {
+    int device = 0;
     uint32_t C = 0, nh = 0, ni = 0;
     std::vector<uint64_t> bounds;  // C * (ni + 1), sorted per channel
     uint64_t n_tiles = 0, n_slots = 0;
@@ -123,12 +108,12 @@ struct mh_sweep {
 };
 
 // device operations run on the plan's device: its tables live there
-static int check_device(const mh_plan *p, const char *who)
+static int check_device(int device, const char *who)
 {
     int d = -1;
     MH_HIP(hipGetDevice(&d));
-    if (d != p->device)
-        return fail(MH_ERR_ARG, "%s: plan was created on device %d, the current device is %d", who, p->device, d);
+    if (d != device)
+        return fail(MH_ERR_ARG, "%s: the plan was created on device %d, the current device is %d", who, device, d);
     return MH_OK;
 }
 
@@ -136,6 +121,7 @@ static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, u
                             uint8_t *peak, uint8_t *enc, hipStream_t st, unsigned long long *zero_hist,
                             unsigned long long *zero_bits, uint8_t *skip_dst)
 {
+    const mh_plan_info_t &I = p->h.info;
     mh::CalArgs a;
     a.zero_hist = zero_hist;
     a.zero_bits = zero_bits;
@@ -146,18 +132,18 @@ static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, u
     a.ch_len = p->d_ch_len;
     a.sclv = p->d_sclv;
     a.codes = p->d_codes;
-    a.C = p->info.C;
-    a.S = p->info.S;
-    a.h = p->info.h;
-    a.mode = p->info.mode;
-    a.K = p->info.K;
+    a.C = I.C;
+    a.S = I.S;
+    a.h = I.h;
+    a.mode = I.mode;
+    a.K = I.K;
     a.cutoff = cutoff;
     a.cal_sorted = cal_hist;
     a.peak = peak;
     a.enc = enc;
     a.lut = p->d_lut;
     a.pre_hist = nullptr;
-    if (p->n_cal_tiles) {  // long calibration windows (2^h > kCalDirect): tiled histogram first
+    if (!p->h.cal_tile_ch.empty()) {  // long calibration windows (2^h > kCalDirect): tiled histogram first
         MH_HIP(hipMemsetAsync(p->d_calhist, 0, (size_t)a.C * mh::kHistStride * sizeof(unsigned long long), st));
         mh::HistArgs ha;
         ha.data = data;
@@ -167,7 +153,7 @@ static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, u
         ha.tile_n = p->d_cal_tile_n;
         ha.hist = p->d_calhist;
         ha.tile_slot = nullptr;
-        hipLaunchKernelGGL(mh::k_hist2<4>, dim3((unsigned)p->n_cal_tiles), dim3(256), 0, st, ha, p->info.S);
+        hipLaunchKernelGGL(mh::k_hist2<4>, dim3((unsigned)p->h.cal_tile_ch.size()), dim3(256), 0, st, ha, I.S);
         a.pre_hist = p->d_calhist;
     }
     hipLaunchKernelGGL(mh::k_calibrate, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
@@ -181,46 +167,66 @@ static void launch_hist(const mh::HistArgs &a, uint64_t n_tiles, hipStream_t st)
     hipLaunchKernelGGL(mh::k_hist<NS>, dim3((unsigned)n_tiles), dim3(256), 0, st, a);
 }
 
-int g_ablate = 0;  // debug only (mhdbg_set_ablation); 0 in production
+#ifdef MH_TUNING
+int g_ablate = 0;  // timing-only ablations of the S <= 3 encoder (mhdbg_set_ablation)
+#endif
 
 // The launch helpers double as "prepare" helpers: with this thread-local flag set they only
-// raise the kernel's dynamic-LDS limit (hipFuncSetAttribute) and do not launch.  mh_plan_create
+// raise the kernel's dynamic-LDS limit (hipFuncSetAttribute), check that the kernel has no static
+// LDS (the decoders address their table by raw LDS offset) and do not launch.  mh_plan_create
 // runs them once that way, so mh_encode / mh_decode issue nothing but stream work and stay
 // capturable into a hipGraph.
 thread_local bool g_prepare_only = false;
-static inline bool st_prepare_only_flag() { return g_prepare_only; }
+
+static int prepare_kernel(const void *kern, size_t lds, bool needs_lds_base_0)
+{
+    if (needs_lds_base_0) {
+        hipFuncAttributes fa;
+        MH_HIP(hipFuncGetAttributes(&fa, kern));
+        if (fa.sharedSizeBytes != 0)
+            return fail(MH_ERR_HIP, "decode kernel has %zu bytes of static LDS: its table would not sit at LDS offset 0",
+                        (size_t)fa.sharedSizeBytes);
+    }
+    if (lds > 64 * 1024)
+        MH_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return MH_OK;
+}
 
 template <int LC, int PB, int ABL = 0>
 static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 {
     const size_t lds = ((size_t)mh::kEncSharedDw + 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw)) * sizeof(uint32_t);
     auto kern = mh::k_encode2<LC, PB, ABL>;
-    if (!st_prepare_only_flag()) {
-        hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
-    } else if (lds > 64 * 1024) {  // plan creation: raise the dynamic-LDS limit once, outside any capture
-        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        return MH_OK;
-    } else {
-        return MH_OK;
-    }
+    if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
+    hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+template <int LC, int PB>
+static int launch_encode2w(const mh::Enc2Args &a, hipStream_t st)
+{
+    const size_t lds = 4 * (size_t)mh::enc2w_wave_dwords(a.e.stage_dw) * sizeof(uint32_t);
+    auto kern = mh::k_encode2w<LC, PB>;
+    if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
+    hipLaunchKernelGGL(kern, dim3((a.t.ntask + 3) / 4), dim3(256), lds, st, a);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }
 
 template <int K, int M, int NR, int RL, bool HY>
-static int launch_decode2(const mh::Dec2Args &a, hipStream_t st)
+static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st)
 {
-    const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
-    auto kern = mh::k_decode2<K, M, NR, RL, HY>;
-    if (!st_prepare_only_flag()) {
-        hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
-    } else if (lds > 64 * 1024) {
-        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        return MH_OK;
+    if (wave_tasks) {
+        const size_t lds = 4 * ((size_t)mh::dec2_shared_dwords(a.W, K) + (size_t)NR * 64) * sizeof(uint32_t);
+        auto kern = mh::k_decode2w<K, M, NR, RL, HY>;
+        if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
+        hipLaunchKernelGGL(kern, dim3((a.t.ntask + 3) / 4), dim3(256), lds, st, a);
     } else {
-        return MH_OK;
+        const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
+        auto kern = mh::k_decode2<K, M, NR, RL, HY>;
+        if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, K == 2);
+        hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     }
     MH_HIP(hipGetLastError());
     return MH_OK;
@@ -233,9 +239,16 @@ static inline uint32_t enc_stage_dw(uint32_t maxlen) { return 8 * maxlen < 32 ? 
 
 static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t st)
 {
-    const uint32_t L = p->info.maxlen;
-    const bool pb3 = p->info.S <= 8;  // 3-bit pair packing when every symbol fits 3 bits
-    if (L <= 2 && pb3 && g_ablate) {  // debug ablations of the S<=3 kernel
+    const uint32_t L = p->h.info.maxlen;
+    const bool pb3 = p->h.info.S <= 8;  // 3-bit pair packing when every symbol fits 3 bits
+    if (p->h.use_wave_tasks) {
+        if (L <= 2) return pb3 ? launch_encode2w<0, 3>(a2, st) : launch_encode2w<0, 4>(a2, st);
+        if (L <= 4) return pb3 ? launch_encode2w<1, 3>(a2, st) : launch_encode2w<1, 4>(a2, st);
+        if (L <= 8) return pb3 ? launch_encode2w<2, 3>(a2, st) : launch_encode2w<2, 4>(a2, st);
+        return launch_encode2w<3, 4>(a2, st);
+    }
+#ifdef MH_TUNING
+    if (L <= 2 && pb3 && g_ablate) {
         switch (g_ablate) {
         case 1: return launch_encode2<0, 3, 1>(a2, st);
         case 2: return launch_encode2<0, 3, 2>(a2, st);
@@ -243,6 +256,7 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
         default: return launch_encode2<0, 3, 4>(a2, st);
         }
     }
+#endif
     if (L <= 2) return pb3 ? launch_encode2<0, 3>(a2, st) : launch_encode2<0, 4>(a2, st);
     if (L <= 4) return pb3 ? launch_encode2<1, 3>(a2, st) : launch_encode2<1, 4>(a2, st);
     if (L <= 8) return pb3 ? launch_encode2<2, 3>(a2, st) : launch_encode2<2, 4>(a2, st);
@@ -251,32 +265,25 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
 
 static int dispatch_decode(const mh_plan *p, const mh::Dec2Args &a2, hipStream_t st)
 {
-    const uint32_t L = p->info.maxlen;
-    // window maintenance (decode_staged_chunk): 1 = reload, 0 = branchy top-up, 2 = select top-up.
-    // MH_DEC_RELOAD overrides for tuning; defaults are the measured best (profiles/README.md).
-    static const int force = [] { const char *e = getenv("MH_DEC_RELOAD"); return e ? atoi(e) : -1; }();
-    if (L <= 2) return launch_decode2<4, 4, 17, 1, false>(a2, st);  // worst-case chunk = 1027 words: never oversize
-    // measured (profiles/README.md): select top-up for maxlen 3 and the hybrid table, branchy top-up between
-    const int rl = force >= 0 ? force : (L == 3 || a2.W < 2 * L) ? 2 : 0;
-    if (L == 3)
-        return rl == 1 ? launch_decode2<2, 2, 25, 1, false>(a2, st)
-             : rl == 2 ? launch_decode2<2, 2, 25, 2, false>(a2, st) : launch_decode2<2, 2, 25, 0, false>(a2, st);
-    if (a2.W >= 2 * L)
-        return rl == 1 ? launch_decode2<2, 2, 32, 1, false>(a2, st)
-             : rl == 2 ? launch_decode2<2, 2, 32, 2, false>(a2, st) : launch_decode2<2, 2, 32, 0, false>(a2, st);
+    const uint32_t L = p->h.info.maxlen;
+    const bool wt = p->h.use_wave_tasks;
+    // window maintenance (decode_staged_chunk): 1 = reload, 0 = branchy top-up, 2 = select top-up;
+    // the choices are the measured best per variant (profiles/README.md)
+    if (L <= 2) return launch_decode2<4, 4, 17, 1, false>(a2, wt, st);  // worst-case chunk = 1027 words: never oversize
+    if (L == 3) return launch_decode2<2, 2, 25, 2, false>(a2, wt, st);
+    if (a2.W >= 2 * L) return launch_decode2<2, 2, 32, 0, false>(a2, wt, st);
     // hybrid pair table: W < 2 * maxlen index bits, one-symbol entries flagged
-    if (p->dec_NR == 31)
-        return rl == 2 ? launch_decode2<2, 2, 31, 2, true>(a2, st) : launch_decode2<2, 2, 31, 0, true>(a2, st);
-    return launch_decode2<2, 2, 32, 0, true>(a2, st);
+    if (p->h.dec_NR == 31) return launch_decode2<2, 2, 31, 2, true>(a2, wt, st);
+    return launch_decode2<2, 2, 32, 0, true>(a2, wt, st);
 }
 
 // raise the dynamic-LDS limits of the kernels this plan will launch (once, at plan creation)
 static int prepare_kernels(const mh_plan *p)
 {
     mh::Enc2Args e{};
-    e.e.stage_dw = enc_stage_dw(p->info.maxlen);
+    e.e.stage_dw = enc_stage_dw(p->h.info.maxlen);
     mh::Dec2Args d{};
-    d.W = p->W;
+    d.W = p->h.W;
     g_prepare_only = true;
     int rc = dispatch_encode(p, e, nullptr);
     if (rc == MH_OK) rc = dispatch_decode(p, d, nullptr);
@@ -288,8 +295,10 @@ extern "C" {
 
 int mh_version(void) { return MH_VERSION; }
 
-/* debug hook, not part of the public ABI: selects a timing-only ablation of k_encode2 */
+#ifdef MH_TUNING
+/* tuning builds only: selects a timing-only ablation of k_encode2 */
 void mhdbg_set_ablation(int level) { g_ablate = level; }
+#endif
 
 const char *mh_last_error(void) { return g_err; }
 
@@ -313,14 +322,9 @@ int mh_codebook(const uint8_t *sclv_row, int S, uint16_t *code, uint8_t *len)
 {
     if (!sclv_row || !code || !len || S < 2 || S > MH_LUT_SYMS) return fail(MH_ERR_ARG, "mh_codebook: bad argument");
     uint32_t m;
-    if (check_row(sclv_row, S, &m) != MH_OK)
+    if (mh::check_sclv_row(sclv_row, S, &m) != MH_OK)
         return fail(MH_ERR_SCLV, "SCLV row is not a non-decreasing complete prefix-code length vector");
-    uint32_t c = 0;
-    for (int r = 0; r < S; ++r) {
-        if (r) c = (c + 1) << (sclv_row[r] - sclv_row[r - 1]);
-        code[r] = (uint16_t)c;
-        len[r] = sclv_row[r];
-    }
+    mh::canonical_codes(sclv_row, S, code, len);
     return MH_OK;
 }
 
@@ -338,139 +342,76 @@ int mh_plan_destroy(mh_plan *p)
     void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
-                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_dtab2, p->d_scan,
-                    p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist};
+                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_seg, p->d_dtab2, p->d_scan,
+                    p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
     return MH_OK;
 }
 
-static int plan_build(mh_plan *p, const uint64_t *ch_off, const uint64_t *ch_len,
-                      const uint8_t *sclv)
+// device side of plan creation: upload the planner's tables, allocate the per-channel scratch
+static int plan_upload(mh_plan *p)
 {
-    const mh_plan_info_t &I = p->info;
-    const uint32_t C = I.C, S = I.S, K = I.K;
-    // windows: c = min(2^h, T) (functions_1.py:59-64), e = c + T/2 (get_BR_with_approx_sort.py:180)
-    std::vector<uint64_t> w0(C), w1(C), off(ch_off, ch_off + C), len(ch_len, ch_len + C);
-    std::vector<uint8_t> skip(C, 0);
-    const uint64_t lim = (uint64_t)1 << I.h;
-    uint64_t total = 0, nskip = 0;
-    for (uint32_t c = 0; c < C; ++c) {
-        const uint64_t T = ch_len[c];
-        if (T > p->max_T) p->max_T = T;
-        const uint64_t cut = T < lim ? T : lim, e = cut + T / 2;
-        switch (I.window) {
-        case MH_WIN_REF_HALF:
-            if (e > T) {  // :183-185 skipped, shows up as NaN in the reference
-                skip[c] = 1;
-                w0[c] = w1[c] = cut;
-                ++nskip;
-            } else {
-                w0[c] = cut;
-                w1[c] = e;
-            }
-            break;
-        case MH_WIN_REF_HALF_TRUNC: w0[c] = cut; w1[c] = e > T ? T : e; break;
-        case MH_WIN_AFTER_CAL: w0[c] = cut; w1[c] = T; break;
-        default: w0[c] = 0; w1[c] = T; break;
-        }
-        total += w1[c] - w0[c];
-    }
-    p->info.window_samples = total;
-    p->info.n_skipped = nskip;
-    // segments: seg_chunks chunks each, slot sized for the longest code of any encoder
-    const uint64_t seg_samples = (uint64_t)I.seg_chunks * MH_CHUNK, L = I.maxlen;
-    uint64_t slot = 0;
-    std::vector<uint32_t> tile_ch, tile_n, task_seg0;
-    std::vector<uint8_t> task_n;
-    std::vector<uint64_t> tile_start;
-    for (uint32_t c = 0; c < C; ++c) {
-        const uint64_t n = w1[c] - w0[c];
-        const size_t seg_begin = p->seg_ch.size();
-        for (uint64_t first = 0; first < n; first += seg_samples) {
-            const uint64_t m = n - first < seg_samples ? n - first : seg_samples;
-            const uint64_t full = m / MH_CHUNK, rem = m % MH_CHUNK;
-            uint64_t words = (full + (rem ? 1 : 0)) * MH_HDR_WORDS + full * ((MH_CHUNK * L + 31) / 32);
-            if (rem) words += (rem * L + 31) / 32;
-            words = (words + 31) & ~(uint64_t)31;  // slots start on 128-byte lines
-            p->seg_ch.push_back(c);
-            p->seg_first.push_back(first);
-            p->seg_n.push_back(m);
-            p->seg_off.push_back(slot);
-            slot += words;
-        }
-        for (size_t s0 = seg_begin; s0 < p->seg_ch.size(); s0 += 4) {
-            task_seg0.push_back((uint32_t)s0);
-            task_n.push_back((uint8_t)(p->seg_ch.size() - s0 < 4 ? p->seg_ch.size() - s0 : 4));
-        }
-        for (uint64_t first = 0; first < n; first += kHistTile) {
-            tile_ch.push_back(c);
-            tile_start.push_back(w0[c] + first);
-            tile_n.push_back((uint32_t)(n - first < kHistTile ? n - first : kHistTile));
-        }
-    }
-    // calibration: one wave per channel reads the window directly up to kCalDirect samples (the
-    // reference's range is 2^2..2^10); longer windows go through the tiled histogram kernel
-    std::vector<uint32_t> cal_tile_ch, cal_tile_n;
-    std::vector<uint64_t> cal_tile_start;
-    if (lim > kCalDirect)
-        for (uint32_t c = 0; c < C; ++c) {
-            const uint64_t n = len[c] < lim ? len[c] : lim;
-            for (uint64_t first = 0; first < n; first += kHistTile) {
-                cal_tile_ch.push_back(c);
-                cal_tile_start.push_back(first);
-                cal_tile_n.push_back((uint32_t)(n - first < kHistTile ? n - first : kHistTile));
-            }
-        }
-    p->n_cal_tiles = cal_tile_ch.size();
-    p->info.n_segments = p->seg_ch.size();
-    p->info.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
-    p->n_tiles = tile_ch.size();
-    p->n_tasks = (uint32_t)task_seg0.size();
-    // decode table: K symbols per lookup, W index bits.  maxlen <= 5: W = K * maxlen (<= 10), every
-    // entry holds K whole codewords; longer codes: hybrid pair table of 10 index bits and 31
-    // staging registers, which keeps 4 workgroups per CU (tables + staging <= 40 KiB of LDS).
-    // MH_DEC_W / MH_DEC_NR: tuning overrides (index-bit cap 8..12, staging registers 31|32).
-    p->dec_K = I.maxlen <= 2 ? 4 : 2;
-    p->W = p->dec_K * I.maxlen;
-    p->dec_NR = 32;
-    if (p->dec_K == 2) {
-        static const int w_env = [] { const char *e = getenv("MH_DEC_W"); return e ? atoi(e) : 0; }();
-        static const int nr_env = [] { const char *e = getenv("MH_DEC_NR"); return e ? atoi(e) : 0; }();
-        uint32_t cap = w_env >= 8 && w_env <= 12 ? (uint32_t)w_env : 10u;
-        if (cap < I.maxlen) cap = I.maxlen;  // a flagged entry still holds its first codeword
-        if (p->W > cap) p->W = cap;
-        if (p->W < 2 * I.maxlen) p->dec_NR = nr_env == 32 ? 32 : 31;
-    }
-    // codebooks by rank: bit-reversed code (first code bit at bit 0) | len << 16
-    std::vector<uint32_t> codes((size_t)K * 16, 0);
-    for (uint32_t k = 0; k < K; ++k) {
-        uint16_t code[16];
-        uint8_t ln[16];
-        int rc = mh_codebook(sclv + (size_t)k * S, (int)S, code, ln);
-        if (rc != MH_OK) return rc;
-        for (uint32_t r = 0; r < S; ++r) codes[k * 16 + r] = bitrev(code[r], ln[r]) | ((uint32_t)ln[r] << 16);
-    }
-    std::vector<uint8_t> sc(sclv, sclv + (size_t)K * S);
+    const mh::PlanHost &H = p->h;
+    const uint32_t C = H.info.C;
+    const bool cal = !H.cal_tile_ch.empty();
     int rc;
-    if ((rc = upload(&p->d_ch_off, off)) || (rc = upload(&p->d_ch_len, len)) ||
-        (rc = upload(&p->d_w0, w0)) || (rc = upload(&p->d_w1, w1)) || (rc = upload(&p->d_skip, skip)) ||
-        (rc = upload(&p->d_sclv, sc)) || (rc = upload(&p->d_codes, codes)) ||
-        (rc = upload(&p->d_seg_ch, p->seg_ch)) || (rc = upload(&p->d_seg_first, p->seg_first)) ||
-        (rc = upload(&p->d_seg_n, p->seg_n)) || (rc = upload(&p->d_seg_off, p->seg_off)) ||
-        (rc = upload(&p->d_tile_ch, tile_ch)) || (rc = upload(&p->d_tile_n, tile_n)) ||
-        (rc = upload(&p->d_tile_start, tile_start)) ||
+    if ((rc = upload(&p->d_ch_off, H.ch_off)) || (rc = upload(&p->d_ch_len, H.ch_len)) ||
+        (rc = upload(&p->d_w0, H.w0)) || (rc = upload(&p->d_w1, H.w1)) || (rc = upload(&p->d_skip, H.skip)) ||
+        (rc = upload(&p->d_sclv, H.sclv)) || (rc = upload(&p->d_codes, H.codes)) ||
+        (rc = upload(&p->d_seg_ch, H.seg_ch)) || (rc = upload(&p->d_seg_first, H.seg_first)) ||
+        (rc = upload(&p->d_seg_n, H.seg_n)) || (rc = upload(&p->d_seg_off, H.seg_off)) ||
+        (rc = upload(&p->d_tile_ch, H.tile_ch)) || (rc = upload(&p->d_tile_n, H.tile_n)) ||
+        (rc = upload(&p->d_tile_start, H.tile_start)) ||
         (rc = alloc(&p->d_hist, (size_t)C * mh::kHistStride)) || (rc = alloc(&p->d_peak, C)) ||
         (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_dtab, (size_t)C * mh::kDtab)) ||
         (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
-        (rc = upload(&p->d_task_seg0, task_seg0)) || (rc = upload(&p->d_task_n, task_n)) ||
-        (p->dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << p->W))) ||
-        (rc = alloc(&p->d_scan, p->seg_ch.size() / mh::kScanBlock + 2)) ||
-        (p->n_cal_tiles && ((rc = upload(&p->d_cal_tile_ch, cal_tile_ch)) || (rc = upload(&p->d_cal_tile_n, cal_tile_n)) ||
-                            (rc = upload(&p->d_cal_tile_start, cal_tile_start)) ||
-                            (rc = alloc(&p->d_calhist, (size_t)C * mh::kHistStride)))))
+        (rc = upload(&p->d_task_seg0, H.task_seg0)) || (rc = upload(&p->d_task_n, H.task_n)) ||
+        (H.use_wave_tasks && (rc = upload(&p->d_wave_seg, H.wave_seg))) ||
+        (H.dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << H.W))) ||
+        (rc = alloc(&p->d_scan, H.seg_ch.size() / mh::kScanBlock + 2)) || (rc = alloc(&p->d_err, 1)) ||
+        (cal && ((rc = upload(&p->d_cal_tile_ch, H.cal_tile_ch)) || (rc = upload(&p->d_cal_tile_n, H.cal_tile_n)) ||
+                 (rc = upload(&p->d_cal_tile_start, H.cal_tile_start)) ||
+                 (rc = alloc(&p->d_calhist, (size_t)C * mh::kHistStride)))))
         return rc;
+    return MH_OK;
+}
+
+static int plan_args(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h, uint32_t mode, uint32_t window,
+                     const uint8_t *sclv, uint32_t K, uint32_t seg_chunks, mh_plan_info_t *I)
+{
+    const char *msg = "";
+    uint32_t arg = 0, maxlen = 0;
+    const int rc = mh::plan_check_args(ch_len, C, S, h, mode, window, sclv, K, &maxlen, &msg, &arg);
+    if (rc != MH_OK) return fail(rc, msg, arg);
+    *I = mh_plan_info_t{};
+    I->C = C;
+    I->S = S;
+    I->h = h;
+    I->mode = mode;
+    I->window = window;
+    I->K = K;
+    I->seg_chunks = seg_chunks;  // 0 = the planner chooses
+    I->maxlen = maxlen;
+    return MH_OK;
+}
+
+int mh_plan_query(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h, uint32_t mode, uint32_t window,
+                  const uint8_t *sclv, uint32_t K, uint32_t seg_chunks, mh_plan_info_t *info, uint32_t *seg_ch,
+                  uint64_t *seg_first, uint64_t *seg_n, uint64_t *seg_off, uint64_t seg_cap)
+{
+    if (!ch_len || !sclv || !info) return fail(MH_ERR_ARG, "mh_plan_query: NULL argument");
+    mh::PlanHost H;
+    if (int rc = plan_args(ch_len, C, S, h, mode, window, sclv, K, seg_chunks, &H.info)) return rc;
+    std::vector<uint64_t> off(C, 0);  // offsets do not enter the directory
+    mh::plan_host_build(H, off.data(), ch_len, sclv, plan_tuning());
+    *info = H.info;
+    const size_t n = H.seg_ch.size() < seg_cap ? H.seg_ch.size() : (size_t)seg_cap;
+    if (seg_ch && n) memcpy(seg_ch, H.seg_ch.data(), n * sizeof(uint32_t));
+    if (seg_first && n) memcpy(seg_first, H.seg_first.data(), n * sizeof(uint64_t));
+    if (seg_n && n) memcpy(seg_n, H.seg_n.data(), n * sizeof(uint64_t));
+    if (seg_off && n) memcpy(seg_off, H.seg_off.data(), n * sizeof(uint64_t));
     return MH_OK;
 }
 
@@ -480,38 +421,22 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
 {
     if (!plan || !ch_off || !ch_len || !sclv) return fail(MH_ERR_ARG, "mh_plan_create: NULL argument");
     *plan = nullptr;
-    if (C == 0) return fail(MH_ERR_ARG, "mh_plan_create: C == 0");
-    if (S < 2 || S > MH_LUT_SYMS) return fail(MH_ERR_ARG, "S=%u outside 2..10", S);
-    if (h > 30) return fail(MH_ERR_ARG, "h=%u outside 0..30", h);
-    if (mode > MH_MODE_APPROX) return fail(MH_ERR_ARG, "mode=%u unknown", mode);
-    if (window > MH_WIN_FULL) return fail(MH_ERR_ARG, "window=%u unknown", window);
-    if (K == 0 || K > 255) return fail(MH_ERR_ARG, "K=%u outside 1..255", K);
-    if (seg_chunks == 0) seg_chunks = 2;  // measured sweet spot on MI355X (profiles/)
-    uint32_t maxlen = 0;
-    for (uint32_t k = 0; k < K; ++k) {
-        uint32_t m;
-        if (check_row(sclv + (size_t)k * S, (int)S, &m) != MH_OK)
-            return fail(MH_ERR_SCLV, "SCLV row %u is not a non-decreasing complete code-length vector", k);
-        if (m > maxlen) maxlen = m;
-    }
-    for (uint32_t c = 0; c < C; ++c)
-        if (ch_len[c] == 0)
-            return fail(MH_ERR_EMPTY_CHANNEL, "channel %u has no bins (the reference raises IndexError)", c);
-    int ndev = 0;
+    mh_plan_info_t I;
+    if (int rc = plan_args(ch_len, C, S, h, mode, window, sclv, K, seg_chunks, &I)) return rc;
+    int ndev = 0, dev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(MH_ERR_NO_DEVICE, "no HIP device visible (libmuahuff has no CPU fallback)");
+    MH_HIP(hipGetDevice(&dev));
     mh_plan *p = new (std::nothrow) mh_plan;
     if (!p) return fail(MH_ERR_ARG, "out of host memory");
-    MH_HIP(hipGetDevice(&p->device));
-    p->info.C = C;
-    p->info.S = S;
-    p->info.h = h;
-    p->info.mode = mode;
-    p->info.window = window;
-    p->info.K = K;
-    p->info.seg_chunks = seg_chunks;
-    p->info.maxlen = maxlen;
-    int rc = plan_build(p, ch_off, ch_len, sclv);
+    p->device = dev;
+    p->h.info = I;
+    mh::plan_host_build(p->h, ch_off, ch_len, sclv, plan_tuning());
+    if (p->h.seg_ch.size() > 0xFFFFFFF0ull) {  // segment and task indices are 32-bit on the device
+        mh_plan_destroy(p);
+        return fail(MH_ERR_ARG, "mh_plan_create: %zu segments exceed the 32-bit directory", p->h.seg_ch.size());
+    }
+    int rc = plan_upload(p);
     if (rc == MH_OK) rc = prepare_kernels(p);
     if (rc != MH_OK) {
         mh_plan_destroy(p);
@@ -524,7 +449,7 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
 int mh_plan_info(const mh_plan *plan, mh_plan_info_t *info)
 {
     if (!plan || !info) return fail(MH_ERR_ARG, "mh_plan_info: NULL argument");
-    *info = plan->info;
+    *info = plan->h.info;
     return MH_OK;
 }
 
@@ -532,11 +457,11 @@ int mh_plan_segments(const mh_plan *plan, uint32_t *seg_ch, uint64_t *seg_first,
                      uint64_t *seg_off)
 {
     if (!plan) return fail(MH_ERR_ARG, "mh_plan_segments: NULL plan");
-    const size_t n = plan->seg_ch.size();
-    if (seg_ch && n) memcpy(seg_ch, plan->seg_ch.data(), n * sizeof(uint32_t));
-    if (seg_first && n) memcpy(seg_first, plan->seg_first.data(), n * sizeof(uint64_t));
-    if (seg_n && n) memcpy(seg_n, plan->seg_n.data(), n * sizeof(uint64_t));
-    if (seg_off && n) memcpy(seg_off, plan->seg_off.data(), n * sizeof(uint64_t));
+    const size_t n = plan->h.seg_ch.size();
+    if (seg_ch && n) memcpy(seg_ch, plan->h.seg_ch.data(), n * sizeof(uint32_t));
+    if (seg_first && n) memcpy(seg_first, plan->h.seg_first.data(), n * sizeof(uint64_t));
+    if (seg_n && n) memcpy(seg_n, plan->h.seg_n.data(), n * sizeof(uint64_t));
+    if (seg_off && n) memcpy(seg_off, plan->h.seg_off.data(), n * sizeof(uint64_t));
     return MH_OK;
 }
 
@@ -545,12 +470,12 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
                uint8_t *skipped, void *stream)
 {
     if (!p || !data) return fail(MH_ERR_ARG, "mh_measure: NULL argument");
-    if (int rc_ = check_device(p, "mh_measure")) return rc_;
+    if (int rc_ = check_device(p->device, "mh_measure")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
     int rc = launch_calibrate(p, data, cutoff, cal_hist, pk, en, st, p->d_hist, nullptr, nullptr);
     if (rc) return rc;
-    if (p->n_tiles) {
+    if (!p->h.tile_ch.empty()) {
         mh::HistArgs a;
         a.data = data;
         a.ch_off = p->d_ch_off;
@@ -559,15 +484,16 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
         a.tile_n = p->d_tile_n;
         a.hist = p->d_hist;
         a.tile_slot = nullptr;
-        const unsigned nt = (unsigned)p->n_tiles;
-        if (p->info.S == 2)
-            launch_hist<1>(a, p->n_tiles, st);  // byte-compare kernel: already at the read floor
-        else if (p->info.S == 3)
-            launch_hist<2>(a, p->n_tiles, st);
-        else if (p->info.S <= 8)  // pair-LUT histogram, 3-bit pair packing
-            hipLaunchKernelGGL(mh::k_hist2<3>, dim3(nt), dim3(256), 0, st, a, p->info.S);
+        const uint64_t n_tiles = p->h.tile_ch.size();
+        const unsigned nt = (unsigned)n_tiles;
+        if (p->h.info.S == 2)
+            launch_hist<1>(a, n_tiles, st);  // byte-compare kernel: already at the read floor
+        else if (p->h.info.S == 3)
+            launch_hist<2>(a, n_tiles, st);
+        else if (p->h.info.S <= 8)  // pair-LUT histogram, 3-bit pair packing
+            hipLaunchKernelGGL(mh::k_hist2<3>, dim3(nt), dim3(256), 0, st, a, p->h.info.S);
         else                      // S = 9, 10: 4-bit packing, xor-swizzled
-            hipLaunchKernelGGL(mh::k_hist2<4>, dim3(nt), dim3(256), 0, st, a, p->info.S);
+            hipLaunchKernelGGL(mh::k_hist2<4>, dim3(nt), dim3(256), 0, st, a, p->h.info.S);
         MH_HIP(hipGetLastError());
     }
     mh::FinArgs f;
@@ -578,9 +504,9 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
     f.peak = pk;
     f.enc = en;
     f.sclv = p->d_sclv;
-    f.C = p->info.C;
-    f.S = p->info.S;
-    f.mode = p->info.mode;
+    f.C = p->h.info.C;
+    f.S = p->h.info.S;
+    f.mode = p->h.info.mode;
     f.post = post_hist;
     f.bits = bits;
     f.skipped = skipped;
@@ -589,10 +515,25 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
     return MH_OK;
 }
 
+static mh::TaskArgs task_args(const mh_plan *p)
+{
+    mh::TaskArgs t;
+    if (p->h.use_wave_tasks) {  // one wave per segment, longest first
+        t.task_seg0 = p->d_wave_seg;
+        t.task_n = nullptr;
+        t.ntask = (uint32_t)p->h.wave_seg.size();
+    } else {                    // one workgroup per <= 4 consecutive segments of a channel
+        t.task_seg0 = p->d_task_seg0;
+        t.task_n = p->d_task_n;
+        t.ntask = (uint32_t)p->h.task_seg0.size();
+    }
+    return t;
+}
+
 static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t *seg_words,
                          uint64_t *ch_bits, hipStream_t st)
 {
-    if (p->info.n_segments == 0) return MH_OK;
+    if (p->h.info.n_segments == 0) return MH_OK;
     mh::EncArgs a;
     a.data = data;
     a.ch_off = p->d_ch_off;
@@ -605,13 +546,11 @@ static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uin
     a.payload = payload;
     a.seg_words = seg_words;
     a.ch_bits = reinterpret_cast<unsigned long long *>(ch_bits);
-    a.nseg = (uint32_t)p->info.n_segments;
-    a.stage_dw = enc_stage_dw(p->info.maxlen);
+    a.nseg = (uint32_t)p->h.info.n_segments;
+    a.stage_dw = enc_stage_dw(p->h.info.maxlen);
     mh::Enc2Args a2;
     a2.e = a;
-    a2.t.task_seg0 = p->d_task_seg0;
-    a2.t.task_n = p->d_task_n;
-    a2.t.ntask = p->n_tasks;
+    a2.t = task_args(p);
     return dispatch_encode(p, a2, st);
 }
 
@@ -621,11 +560,11 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
 {
     if (!p || !data || !payload || !seg_words || !ch_bits)
         return fail(MH_ERR_ARG, "mh_encode: NULL argument");
-    if (int rc_ = check_device(p, "mh_encode")) return rc_;
-    if (payload_cap_words < p->info.payload_cap_words)
+    if (int rc_ = check_device(p->device, "mh_encode")) return rc_;
+    if (payload_cap_words < p->h.info.payload_cap_words)
         return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
                     (unsigned long long)payload_cap_words,
-                    (unsigned long long)p->info.payload_cap_words);
+                    (unsigned long long)p->h.info.payload_cap_words);
     hipStream_t st = (hipStream_t)stream;
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
     int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st, nullptr,
@@ -640,26 +579,26 @@ int mh_encode_preset(mh_plan *p, const uint8_t *data, const uint8_t *peak, const
 {
     if (!p || !data || !peak || !enc || !payload || !seg_words || !ch_bits)
         return fail(MH_ERR_ARG, "mh_encode_preset: NULL argument");
-    if (int rc_ = check_device(p, "mh_encode_preset")) return rc_;
-    if (payload_cap_words < p->info.payload_cap_words)
+    if (int rc_ = check_device(p->device, "mh_encode_preset")) return rc_;
+    if (payload_cap_words < p->h.info.payload_cap_words)
         return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
                     (unsigned long long)payload_cap_words,
-                    (unsigned long long)p->info.payload_cap_words);
+                    (unsigned long long)p->h.info.payload_cap_words);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mh::k_lut_preset, dim3((p->info.C + 15) / 16), dim3(256), 0, st, peak, enc,
-                       (const uint32_t *)p->d_codes, p->info.C, p->info.S, p->info.mode, p->info.K, p->d_lut,
+    hipLaunchKernelGGL(mh::k_lut_preset, dim3((p->h.info.C + 15) / 16), dim3(256), 0, st, peak, enc,
+                       (const uint32_t *)p->d_codes, p->h.info.C, p->h.info.S, p->h.info.mode, p->h.info.K, p->d_lut,
                        reinterpret_cast<unsigned long long *>(ch_bits), (uint8_t *)nullptr, (uint8_t *)nullptr);
     MH_HIP(hipGetLastError());
     return encode_common(p, data, payload, seg_words, ch_bits, st);
 }
 
-int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, const uint8_t *peak,
-              const uint8_t *enc, uint8_t *out, void *stream)
+int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const uint64_t *seg_off,
+              const uint8_t *peak, const uint8_t *enc, uint8_t *out, void *stream)
 {
     if (!p || !payload || !peak || !enc || !out) return fail(MH_ERR_ARG, "mh_decode: NULL argument");
-    if (int rc_ = check_device(p, "mh_decode")) return rc_;
+    if (int rc_ = check_device(p->device, "mh_decode")) return rc_;
     hipStream_t st = (hipStream_t)stream;
-    if (p->info.n_segments == 0) return MH_OK;
+    if (p->h.info.n_segments == 0) return MH_OK;
     mh::DecArgs a;
     a.payload = payload;
     a.ch_off = p->d_ch_off;
@@ -671,30 +610,103 @@ int mh_decode(mh_plan *p, const uint32_t *payload, const uint64_t *seg_off, cons
     a.dtab = p->d_dtab;
     a.dlen = p->d_dlen;
     a.out = out;
-    a.nseg = (uint32_t)p->info.n_segments;
+    a.nseg = (uint32_t)p->h.info.n_segments;
+    a.payload_words = payload_words;
+    a.err = p->d_err;
     mh::Dtab2Args t2;
     t2.peak = peak;
     t2.enc = enc;
     t2.sclv = p->d_sclv;
     t2.codes = p->d_codes;
-    t2.C = p->info.C;
-    t2.S = p->info.S;
-    t2.mode = p->info.mode;
-    t2.W = p->W;
-    t2.K = p->dec_K;
+    t2.C = p->h.info.C;
+    t2.S = p->h.info.S;
+    t2.mode = p->h.info.mode;
+    t2.W = p->h.W;
+    t2.K = p->h.dec_K;
+    t2.nK = p->h.info.K;
     t2.dtab2 = p->d_dtab2;
     t2.dtab = p->d_dtab;
     t2.dlen = p->d_dlen;
+    t2.err = p->d_err;  // cleared here, set by a decoder wave that had to abandon a segment
     hipLaunchKernelGGL(mh::k_build_dtab2, dim3(t2.C), dim3(256), 0, st, t2);
     MH_HIP(hipGetLastError());
     mh::Dec2Args a2;
     a2.d = a;
-    a2.t.task_seg0 = p->d_task_seg0;
-    a2.t.task_n = p->d_task_n;
-    a2.t.ntask = p->n_tasks;
+    a2.t = task_args(p);
     a2.dtab2 = p->d_dtab2;
-    a2.W = p->W;
+    a2.W = p->h.W;
     return dispatch_decode(p, a2, st);
+}
+
+int mh_decode_status(mh_plan *p, uint32_t *flags, void *stream)
+{
+    if (!p || !flags) return fail(MH_ERR_ARG, "mh_decode_status: NULL argument");
+    if (int rc_ = check_device(p->device, "mh_decode_status")) return rc_;
+    MH_HIP(hipMemcpyAsync(flags, p->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return MH_OK;
+}
+
+int mh_validate_stream(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h, uint32_t mode, uint32_t window,
+                       const uint8_t *sclv, uint32_t K, uint32_t seg_chunks, const uint32_t *payload,
+                       uint64_t payload_words, const uint64_t *seg_words, uint64_t n_segments,
+                       const uint8_t *peak, const uint8_t *enc)
+{
+    if (!ch_len || !sclv || !payload || !seg_words || !peak || !enc)
+        return fail(MH_ERR_ARG, "mh_validate_stream: NULL argument");
+    if (seg_chunks == 0) return fail(MH_ERR_ARG, "mh_validate_stream: a stored stream names its seg_chunks");
+    mh::PlanHost H;
+    if (int rc = plan_args(ch_len, C, S, h, mode, window, sclv, K, seg_chunks, &H.info)) return rc;
+    std::vector<uint64_t> off(C, 0);
+    mh::plan_host_build(H, off.data(), ch_len, sclv);
+    if (H.seg_ch.size() != n_segments)
+        return fail(MH_ERR_STREAM, "directory has %llu segments, the layout implies %zu",
+                    (unsigned long long)n_segments, H.seg_ch.size());
+    for (uint32_t c = 0; c < C; ++c)
+        if (peak[c] >= S || enc[c] >= K)
+            return fail(MH_ERR_STREAM, "channel %u: (peak %u, encoder %u) outside (S=%u, K=%u)", c, peak[c], enc[c], S, K);
+    uint64_t pos = 0;
+    for (size_t s = 0; s < H.seg_ch.size(); ++s) {
+        const uint64_t end = pos + seg_words[s];
+        if (end < pos || end > payload_words)
+            return fail(MH_ERR_STREAM, "segment %zu ends at word %llu, the payload has %llu", s,
+                        (unsigned long long)end, (unsigned long long)payload_words);
+        const uint8_t *row = sclv + (size_t)enc[H.seg_ch[s]] * S;
+        const uint64_t maxlen = row[S - 1];
+        uint64_t left = H.seg_n[s];
+        while (left) {
+            const uint64_t m = left < MH_CHUNK ? left : MH_CHUNK;
+            if (pos >= end) return fail(MH_ERR_STREAM, "segment %zu is shorter than its chunk headers say", s);
+            const uint32_t w0 = payload[pos];
+            const uint32_t mn = w0 & 0xFFFu, w = (w0 >> 12) & 15u;
+            if (w > 12) return fail(MH_ERR_STREAM, "segment %zu: chunk header field width %u above 12", s, w);
+            const uint64_t hw = (16u + 64u * w + 31u) >> 5;
+            if (pos + hw > end) return fail(MH_ERR_STREAM, "segment %zu: chunk header runs past the segment", s);
+            uint64_t sum = 0, longest = 0;
+            for (uint32_t l = 0; l < 64; ++l) {
+                uint64_t f = 0;
+                if (w) {
+                    const uint32_t fb = 16u + l * w;
+                    uint64_t v = payload[pos + (fb >> 5)];
+                    if ((fb & 31) + w > 32) v |= (uint64_t)payload[pos + (fb >> 5) + 1] << 32;
+                    f = (v >> (fb & 31)) & ((1u << w) - 1u);
+                }
+                sum += mn + f;
+                if (mn + f > longest) longest = mn + f;
+            }
+            // every codeword has 1..maxlen bits; a sub-stream holds <= 256 samples
+            if (longest > 256 * maxlen || sum > m * maxlen || sum < m)
+                return fail(MH_ERR_STREAM, "segment %zu: sub-stream lengths impossible for this code", s);
+            pos += hw + ((sum + 31) >> 5);
+            left -= m;
+        }
+        if (pos != end) return fail(MH_ERR_STREAM, "segment %zu: chunk sizes do not add up to its %llu words", s,
+                                    (unsigned long long)seg_words[s]);
+    }
+    if (pos != payload_words)
+        return fail(MH_ERR_STREAM, "payload has %llu words, the directory accounts for %llu",
+                    (unsigned long long)payload_words, (unsigned long long)pos);
+    return MH_OK;
 }
 
 int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, uint32_t *dense,
@@ -702,9 +714,9 @@ int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, u
 {
     if (!p || !payload || !seg_words || !dense || !dense_off || !total_words)
         return fail(MH_ERR_ARG, "mh_compact: NULL argument");
-    if (int rc_ = check_device(p, "mh_compact")) return rc_;
+    if (int rc_ = check_device(p->device, "mh_compact")) return rc_;
     hipStream_t st = (hipStream_t)stream;
-    const uint64_t nseg = p->info.n_segments;
+    const uint64_t nseg = p->h.info.n_segments;
     const uint64_t nblocks = (nseg + mh::kScanBlock - 1) / mh::kScanBlock;
     if (nblocks <= 1) {
         hipLaunchKernelGGL(mh::k_scan_small, dim3(1), dim3(256), 0, st, seg_words, nseg, dense_off, total_words);
@@ -852,8 +864,11 @@ int mh_sweep_create(mh_sweep **sweep, const uint64_t *ch_off, const uint64_t *ch
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(MH_ERR_NO_DEVICE, "no HIP device visible (libmuahuff has no CPU fallback)");
+    int dev = 0;
+    MH_HIP(hipGetDevice(&dev));
     mh_sweep *w = new (std::nothrow) mh_sweep;
     if (!w) return fail(MH_ERR_ARG, "out of host memory");
+    w->device = dev;
     w->C = C;
     w->nh = nh;
     w->ni = 2 * nh + 1;
@@ -883,11 +898,11 @@ int mh_sweep_create(mh_sweep **sweep, const uint64_t *ch_off, const uint64_t *ch
         for (uint32_t j = 0; j < w->ni; ++j) {
             const uint64_t lo = b[j], hi = b[j + 1], slot = (uint64_t)c * w->ni + j;
             slot_len[slot] = hi - lo;
-            for (uint64_t first = lo; first < hi; first += kHistTile) {
+            for (uint64_t first = lo; first < hi; first += mh::kHistTileBytes) {
                 tile_ch.push_back(c);
                 tile_slot.push_back((uint32_t)slot);
                 tile_start.push_back(first);
-                tile_n.push_back((uint32_t)(hi - first < kHistTile ? hi - first : kHistTile));
+                tile_n.push_back((uint32_t)(hi - first < mh::kHistTileBytes ? hi - first : mh::kHistTileBytes));
             }
         }
     }
@@ -916,6 +931,7 @@ int mh_sweep_info(const mh_sweep *w, uint32_t *n_intervals, uint64_t *bounds)
 int mh_sweep_run(mh_sweep *w, const uint8_t *data, uint64_t *hist, void *stream)
 {
     if (!w || !data || !hist) return fail(MH_ERR_ARG, "mh_sweep_run: NULL argument");
+    if (int rc_ = check_device(w->device, "mh_sweep_run")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     MH_HIP(hipMemsetAsync(w->d_scratch, 0, (size_t)w->n_slots * mh::kHistStride * sizeof(unsigned long long), st));
     if (w->n_tiles) {
@@ -933,6 +949,30 @@ int mh_sweep_run(mh_sweep *w, const uint8_t *data, uint64_t *hist, void *stream)
     hipLaunchKernelGGL(mh::k_sweep_finalize, dim3((unsigned)((w->n_slots + 255) / 256)), dim3(256), 0, st,
                        (const unsigned long long *)w->d_scratch, (const uint64_t *)w->d_slot_len,
                        (uint32_t)w->n_slots, hist);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_power_draws(const double *br, uint32_t n_br, const int32_t *idx, uint32_t Z, uint64_t n_draws,
+                   double comm_energy, double per_channels, double static_power, double *x, uint64_t x_stride,
+                   void *stream)
+{
+    if (!br || !idx || !x || n_br == 0 || x_stride == 0) return fail(MH_ERR_ARG, "mh_power_draws: bad argument");
+    if (n_draws == 0) return MH_OK;
+    if (n_draws > 0x7FFFFFFFull * 256) return fail(MH_ERR_ARG, "mh_power_draws: too many draws for one launch");
+    hipLaunchKernelGGL(mh::k_power_draws, dim3((unsigned)((n_draws + 255) / 256)), dim3(256), 0, (hipStream_t)stream, br,
+                       idx, Z, n_draws, comm_energy, per_channels, static_power, x, x_stride);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_reduce_rows(const double *vals, const uint64_t *row_off, uint64_t n_rows, double *sum, double *mx, void *stream)
+{
+    if (!vals || !row_off || !sum || !mx) return fail(MH_ERR_ARG, "mh_reduce_rows: NULL argument");
+    if (n_rows == 0) return MH_OK;
+    if (n_rows > 0x7FFFFFFFull * 256) return fail(MH_ERR_ARG, "mh_reduce_rows: too many rows for one launch");
+    hipLaunchKernelGGL(mh::k_reduce_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vals,
+                       row_off, n_rows, sum, mx);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }

@@ -73,7 +73,10 @@ def gather_payload_pipelined(blocks, dst=0, group=None):
     tensor.  Producing an item should only ENQUEUE device work (encode + compact); this
     function pulls block b+1 from the iterable before it reads block b's size, so with RCCL
     (sends run on the communicator's own stream) the copy overlaps the next encode.  Every rank
-    must yield the same number of blocks.
+    must yield the same number of blocks.  Because block b+1 is enqueued before block b's words
+    and size are read, EVERY in-flight block needs its own ``dense`` and ``total_words`` buffers:
+    a producer that recycles one buffer per shape (stream.StreamEncoder.encode_block_device) must
+    clone them before yielding.
 
     Returns on dst ``(payload, offs)`` with the words in rank-major, block-minor (= channel)
     order and ``offs[r][b]`` the word offset of rank r's block b (plus a final total at

@@ -4,7 +4,7 @@ Same three functions, same signatures, return types and in-place side effects, s
 ``from functions_1 import *`` in reference-shaped scripts keeps working (it also leaks ``np``
 and ``math`` like the original).  ``approx_sort`` and
 ``online_histogram_w_sat_based_nb_of_samples`` are O(S) / closed-form host logic;
-``bin_MUA_data`` runs on the GPU (mh_rebin).
+``bin_MUA_data`` runs on the GPU (mh_deinterleave + mh_rebin).
 """
 import math  # noqa: F401  (leaked by the reference module)
 
@@ -15,35 +15,46 @@ __all__ = ["bin_MUA_data", "online_histogram_w_sat_based_nb_of_samples", "approx
 
 def bin_MUA_data(MUA, bin_res):
     """Sum ``bin_res`` consecutive rows of a [T x C] count matrix -> int [ceil(T/bin_res) x C]
-    (reference: functions_1.py:11-24).  Counts are carried as uint8 on the GPU like the
-    reference's MATLAB-binned inputs; values above 255 in ``MUA`` are rejected."""
-    import torch
-
-    from . import _lib
-    from .codec import _ptr, _stream
-    from .container import layout
+    (reference: functions_1.py:11-24), on the GPU: the matrix is the time-major layout
+    mh_deinterleave reads, and mh_rebin sums each channel.  Any integer dtype is accepted: values
+    outside 0..255 are split into byte planes (after subtracting the minimum), every plane is
+    summed on the GPU and the planes are recombined exactly in int64.  Like the reference, needs at
+    least 2 rows and 2 columns (it indexes MUA[:,1] and MUA[1,:]).  Deviations: non-integer dtypes
+    raise TypeError (the reference would sum floats and truncate), bin_res above 4096 raises
+    MuaHuffError (mh_rebin's limit; the reference's bin periods are 5..100)."""
+    from .container import ChannelSet
 
     MUA = np.asarray(MUA)
     if MUA.ndim != 2:
         raise IndexError("too many indices for array")  # MUA[:,1] in the reference
-    if MUA.size and (MUA.min() < 0 or MUA.max() > 255):
-        raise ValueError("bin_MUA_data: counts must fit uint8 (the GPU container is uint8)")
     T, C = MUA.shape
+    if C < 2:
+        raise IndexError("index 1 is out of bounds for axis 1 with size %d" % C)
+    if T < 2:
+        raise IndexError("index 1 is out of bounds for axis 0 with size %d" % T)
+    if MUA.dtype != np.bool_ and not np.issubdtype(MUA.dtype, np.integer):
+        raise TypeError("bin_MUA_data: integer counts expected, got %s" % MUA.dtype)
     bin_res = int(bin_res)
     nb = math.ceil(T / bin_res)
-    off, ln, total = layout([T] * C)
-    host = np.zeros(total + 16, np.uint8)
-    for c in range(C):
-        host[int(off[c]):int(off[c]) + T] = MUA[:, c]
-    dev = torch.device("cuda", torch.cuda.current_device())
-    d = torch.from_numpy(host).to(dev)
-    out = torch.zeros(C * nb, dtype=torch.int32, device=dev)
-    in_off = torch.from_numpy(off.astype(np.int64)).to(dev)
-    in_len = torch.from_numpy(ln.astype(np.int64)).to(dev)
-    out_off = torch.arange(C, dtype=torch.int64, device=dev) * nb
-    _lib.check(_lib.lib().mh_rebin(_ptr(d), _ptr(in_off), _ptr(in_len), C, T, bin_res, 0, _ptr(out),
-                                   _ptr(out_off), _stream()))
-    return out.cpu().numpy().reshape(C, nb).T.astype(int)
+    lo = int(MUA.min())
+    v = MUA.astype(np.int64) - lo if lo < 0 or int(MUA.max()) > 255 else MUA
+    top = int(v.max())
+    total = np.zeros((nb, C), dtype=np.int64)
+    plane, shift = 0, 0
+    while True:
+        byte = np.ascontiguousarray((v >> shift) & 0xFF if top > 255 else v, dtype=np.uint8)
+        cs = ChannelSet.from_time_major(byte)
+        sums, off, n = cs.rebin(bin_res, saturate=False)
+        h = sums.cpu().numpy()
+        total += (h[:nb * C].reshape(C, nb).T.astype(np.int64)) << shift
+        plane, shift = plane + 1, shift + 8
+        if (top >> shift) == 0:
+            break
+    if v is not MUA and lo != 0:  # undo the offset: every bin holds bin_res rows, the last one the rest
+        rows = np.full(nb, bin_res, dtype=np.int64)
+        rows[-1] = T - (nb - 1) * bin_res
+        total += lo * rows[:, None]
+    return total.astype(int)
 
 
 def online_histogram_w_sat_based_nb_of_samples(data_in, sample_val_cutoff, max_firing_rate):

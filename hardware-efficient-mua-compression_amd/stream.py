@@ -60,8 +60,11 @@ class StreamEncoder:
     def encode_block_device(self, block):
         """block: [Tb, C] time-major counts (device tensor or host array).  Enqueues
         de-interleave + preset encode + compaction on the current stream and returns
-        (dense Encoded, total_words tensor, slot) without synchronising; the buffers belong to
-        the shape's slot and are overwritten by the next block of the same shape."""
+        (dense Encoded, total_words tensor, slot) without synchronising.  The buffers (dense
+        words, sizes, total) belong to the shape's slot and are OVERWRITTEN by the next block of
+        the same shape: a consumer that keeps a block in flight while the next one is enqueued
+        (dist.gather_payload_pipelined) must copy them out -- or read the total and record an
+        event -- before asking for the next block."""
         import ctypes as ct
 
         from . import _lib
@@ -93,7 +96,7 @@ class StreamEncoder:
         plan, cs, enc = slot["plan"], slot["cs"], slot["enc"]
         torch.cuda.synchronize()
         total = int(tot.item())
-        hdr = container_io.make_header(self.S, 0, self.mode, WIN_FULL, self.seg_chunks, self.sclv)
+        hdr = container_io.make_header(self.S, 0, self.mode, WIN_FULL, plan.seg_chunks, self.sclv)
         hdr["preset"] = True
         return container_io.Compressed(hdr, cs.ch_len.copy(), enc.peak.cpu().numpy(), enc.enc.cpu().numpy(),
                                        enc.skipped.cpu().numpy(), enc.ch_bits.cpu().numpy().astype(np.uint64),

@@ -16,8 +16,8 @@
  *     allocates and owns every buffer;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); device work is
  *     enqueued asynchronously on it and nothing in mh_measure/mh_encode/mh_decode/
- *     mh_compact/mh_synth_poisson/mh_rebin/mh_deinterleave/mh_interleave synchronises, allocates or frees, so they can
- *     be captured into a hipGraph;
+ *     mh_compact/mh_synth_poisson/mh_rebin/mh_deinterleave/mh_interleave/mh_power_draws/
+ *     mh_reduce_rows synchronises, allocates or frees, so they can be captured into a hipGraph;
  *   - a plan is bound to the device that was current when it was created and may be used
  *     from one stream at a time (it owns per-channel scratch tables).
  */
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MH_VERSION 101 /* 0.1.1 ; container format revision 2 */
+#define MH_VERSION 102 /* 0.1.2 ; container format revision 2 */
 
 /* ---- error codes -------------------------------------------------------------------- */
 #define MH_OK 0
@@ -42,6 +42,7 @@ extern "C" {
 #define MH_ERR_CAPACITY (-4)      /* payload buffer smaller than mh_plan_info.payload_cap_words */
 #define MH_ERR_HIP (-5)           /* a HIP runtime call failed (message has the HIP error) */
 #define MH_ERR_NO_DEVICE (-6)     /* no gfx950 device visible: there is NO CPU fallback */
+#define MH_ERR_STREAM (-7)        /* mh_validate_stream: the stored stream is inconsistent / corrupt */
 
 /* ---- container geometry (format revision 2; the reference has no bitstream, so this is
  *      build-defined -- see DESIGN.md "Container") ----------------------------------- */
@@ -100,7 +101,10 @@ int mh_approx_sort_perm(int S, int peak, uint8_t *idx);
  * design point: S (symbols 0..S-1), h (calibration window 2^h samples), mapper mode,
  * window rule, K candidate encoders given as SCLV rows (host, K*S bytes, row order =
  * encoder index, first-min tie-break as np.argmin).  Precomputes windows, the segment
- * directory and codebooks and uploads them.  ch_off, ch_len, sclv: host. */
+ * directory and codebooks and uploads them.  ch_off, ch_len, sclv: host.
+ * seg_chunks = chunks per segment (the unit one wavefront encodes / decodes); 0 lets the planner
+ * choose (2, or 1 for small inputs -- mh_plan_info reports the choice, which a stored stream must
+ * carry: segment boundaries are part of the format). */
 int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
                    uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
                    uint32_t K, uint32_t seg_chunks);
@@ -110,6 +114,13 @@ int mh_plan_info(const mh_plan *plan, mh_plan_info_t *info);
  * channel, first sample (relative to the window start), sample count, slot offset (words) */
 int mh_plan_segments(const mh_plan *plan, uint32_t *seg_ch, uint64_t *seg_first,
                      uint64_t *seg_n, uint64_t *seg_off);
+/* The planner without a device (pure host arithmetic, no GPU needed): what mh_plan_create would
+ * report for this layout, to size buffers ahead of time or to rebuild the directory of a stored
+ * stream.  info is filled; the directory arrays (may be NULL) receive at most seg_cap entries. */
+int mh_plan_query(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h, uint32_t mode,
+                  uint32_t window, const uint8_t *sclv, uint32_t K, uint32_t seg_chunks,
+                  mh_plan_info_t *info, uint32_t *seg_ch, uint64_t *seg_first, uint64_t *seg_n,
+                  uint64_t *seg_off, uint64_t seg_cap);
 
 /* ---- device operations ---------------------------------------------------------------- */
 /* Everything the reference computes per validation channel at one (S, h):
@@ -149,12 +160,30 @@ int mh_encode_preset(mh_plan *plan, const uint8_t *data, const uint8_t *peak, co
 /* Inverse of mh_encode: writes clip(x) = min(x, S-1) for every window sample into `out`
  * (same channel layout as the plan's data buffer; bytes outside the windows are left
  * untouched).  seg_off (device, words) = where each segment starts in `payload`; NULL means
- * the plan's slot offsets.  payload must stay readable 4 words past the last segment.
- * The kernel follows the chunk headers it finds: hand it streams this library produced, and
- * check streams from storage first (hardware-efficient-mua-compression_amd/container_io.py:
- * validate() walks every chunk header on the host and rejects anything inconsistent). */
-int mh_decode(mh_plan *plan, const uint32_t *payload, const uint64_t *seg_off,
+ * the plan's slot offsets.  payload_words = words readable at `payload` (the dense stream plus
+ * 4 words of slack, or the plan's payload_cap_words).
+ * Memory-safe on ANY stream: the kernel follows the chunk headers it finds, but every read it
+ * derives from them is checked against payload_words first; a segment whose headers point outside
+ * is abandoned (its remaining output is not written) and the plan's status word is set --
+ * mh_decode_status.  Stores only go to the plan's own window positions.  (peak, enc) values out
+ * of range decode as 0.  Streams from storage should still be checked with mh_validate_stream,
+ * which also detects inconsistencies that stay inside the buffer. */
+int mh_decode(mh_plan *plan, const uint32_t *payload, uint64_t payload_words, const uint64_t *seg_off,
               const uint8_t *peak, const uint8_t *enc, uint8_t *out, void *stream);
+/* flags (host) <- 0 when the last mh_decode on this plan read only inside its payload, else 1.
+ * Synchronises `stream`. */
+int mh_decode_status(mh_plan *plan, uint32_t *flags, void *stream);
+
+/* Host-side structural check of a stored stream (no GPU needed; all pointers host): rebuilds the
+ * directory from (ch_len, h, window, seg_chunks), walks every chunk header of every segment of the
+ * DENSE payload (segment s starts at word sum(seg_words[:s])) and verifies that header sizes,
+ * sub-stream lengths (possible for the channel's code) and chunk sizes add up exactly to
+ * seg_words and payload_words, and that (peak, enc) are in range.  MH_ERR_STREAM + mh_last_error
+ * name the first inconsistency. */
+int mh_validate_stream(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h, uint32_t mode,
+                       uint32_t window, const uint8_t *sclv, uint32_t K, uint32_t seg_chunks,
+                       const uint32_t *payload, uint64_t payload_words, const uint64_t *seg_words,
+                       uint64_t n_segments, const uint8_t *peak, const uint8_t *enc);
 
 /* Pack the used words of all segments back to back (directory order) for storage or for
  * the RCCL gather: dense_off[s] = exclusive prefix of seg_words, total_words[0] = sum. */
@@ -205,6 +234,24 @@ int mh_sweep_destroy(mh_sweep *sweep);
 int mh_sweep_info(const mh_sweep *sweep, uint32_t *n_intervals, uint64_t *bounds);
 /* hist (device): C * n_intervals * MH_SWEEP_BINS u64 counts, [channel][interval][bin] */
 int mh_sweep_run(mh_sweep *sweep, const uint8_t *data, uint64_t *hist, void *stream);
+
+/* ---- result consumers (the reference's Analyse results/ scripts), float64, bit-exact with NumPy --
+ * Sums follow NumPy's pairwise summation order, so results equal np.sum / np.mean bit for bit.
+ *
+ * mh_power_draws: Analyse results/max_nb_channels_p_value_power_budget.py:100-105.  For every
+ * draw d < n_draws:  x[d*x_stride] += comm_energy * sum_j br[idx[j*n_draws + d]] + per_channels
+ * + static_power  (per_channels = nb_channels * (ADC_power + chan_processing_power), computed by
+ * the caller in float64).  idx: [Z][n_draws] int32 channel indices < n_br, drawn by the caller
+ * (the reference draws them with np.random.choice; the stream of a seeded legacy RNG can only
+ * be reproduced on the host).  br, idx, x: device. */
+int mh_power_draws(const double *br, uint32_t n_br, const int32_t *idx, uint32_t Z, uint64_t n_draws,
+                   double comm_energy, double per_channels, double static_power, double *x,
+                   uint64_t x_stride, void *stream);
+/* mh_reduce_rows: Analyse results/integrate_BR_and_BDP_results_into_excel.py:118-119.  Row r =
+ * vals[row_off[r] .. row_off[r+1]): sum[r] = np.sum(row) (pairwise), mx[r] = np.max(row) (NaN if
+ * any element is NaN, NaN for an empty row).  All pointers device; row_off has n_rows+1 entries. */
+int mh_reduce_rows(const double *vals, const uint64_t *row_off, uint64_t n_rows, double *sum,
+                   double *mx, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,8 @@ What is executed from /root/reference/"Compressing data":
   * get_BR_no_sort.py            nb_CV_iterations, how_many_channels_Sabes), on a temporary
   * test_chosen_system.py        tree whose file names contain the literal backslashes the
                                  scripts build with '\\' joins
+and from /root/reference/"Analyse results":
+  * max_nb_channels_p_value_power_budget.py   exec'd with root_directory and nb_random_CVs patched
 The reference's Stored_SCLVs_S_<S>.pkl files are NOT unpickled: their float64 rows are read
 with pickletools.genops (a disassembler; executes nothing) and re-written as our own pickles
 for the exec'd scripts to load.
@@ -75,6 +77,19 @@ def tables():
             _d, i = ref_f1.online_histogram_w_sat_based_nb_of_samples(x, 2 ** h, S - 1)
             out["cutoff"].append({"T": T, "cutoff": 2 ** h, "S": S, "i": int(i),
                                   "x": [int(v) for v in x0], "x_after": [int(v) for v in x]})
+    # bin_MUA_data (functions_1.py:11-24): ragged T incl. T < bin_res, the reference's bin periods,
+    # uint8 counts and wider integer counts; its own generator, so the entries above keep their values
+    rng2 = np.random.RandomState(12)
+    out["bin_MUA"] = []
+    for T, C, r in ((2, 2, 1), (2, 2, 5), (7, 3, 5), (100, 2, 10), (101, 4, 10), (999, 3, 50), (1000, 2, 50),
+                    (1001, 2, 100), (57, 5, 100), (256, 3, 1), (4097, 2, 5), (333, 2, 20)):
+        MUA = rng2.randint(0, 40, size=(T, C)).astype(np.uint8)
+        out["bin_MUA"].append({"T": T, "C": C, "r": r, "dtype": "uint8", "MUA": MUA.ravel().tolist(),
+                               "out": ref_f1.bin_MUA_data(MUA, r).ravel().tolist()})
+    for T, C, r in ((64, 2, 5), (130, 3, 10)):
+        MUA = rng2.randint(-300, 70000, size=(T, C)).astype(np.int64)
+        out["bin_MUA"].append({"T": T, "C": C, "r": r, "dtype": "int64", "MUA": MUA.ravel().tolist(),
+                               "out": ref_f1.bin_MUA_data(MUA, r).ravel().tolist()})
     return out
 
 
@@ -230,6 +245,68 @@ def sweeps(sclv):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def power_budget(sclv):
+    """Analyse results/max_nb_channels_p_value_power_budget.py run as it stands (only root_directory
+    and nb_random_CVs patched) on BRs_S_3_BP_50_CV_{1..4}.pkl files that the reference's
+    get_BR_with_approx_sort.py wrote a moment earlier from a seeded synthetic training set.
+    Stores the per-CV BR vectors the script reads (:93), its x (:111), exceed counts (:118) and
+    raw-MUA power (:110)."""
+    rng = np.random.RandomState(77)
+
+    def chan(T, rate):
+        return np.minimum(rng.poisson(rate, size=T), 255).astype(np.uint8)
+
+    flint = [chan(int(rng.randint(2500, 4000)), float(np.exp(rng.uniform(np.log(0.35), np.log(1.6))))) for _ in range(36)]
+    sabes = [chan(int(rng.randint(2500, 4000)), float(np.exp(rng.uniform(np.log(0.35), np.log(1.6))))) for _ in range(48)]
+    train = {"all_binned_data": [[flint, sabes]], "bin_vector": [50], "datasets": ["Flint", "Sabes"]}
+    params = {"nb_random_CVs": 400, "seed_sweep": 99, "seed_draws": 4242}
+    tmp = tempfile.mkdtemp(prefix="mh_golden_pb_")
+    try:
+        root = os.path.join(tmp, "root")
+        os.makedirs(root)
+        fmt, scl = os.path.join(tmp, "Formatted"), os.path.join(tmp, "SCLV")
+        res_a, res_n = os.path.join(tmp, "res_approx"), os.path.join(tmp, "res_nosort")
+        with open(root + "\\directories.txt", "w") as f:
+            f.write("Formatted_data_path = '%s'\nSCLV_path = '%s'\nBR_no_sort_results = '%s'\n"
+                    "BR_approx_sort_results = '%s'\n" % (fmt, scl, res_n, res_a))
+        with open(fmt + "\\all_binned_data_train.pkl", "wb") as f:
+            pickle.dump(train, f)
+        for S in range(2, 11):
+            with open(scl + "\\Stored_SCLVs_S_%d.pkl" % S, "wb") as f:
+                pickle.dump([np.array(r, dtype=np.float64) for r in sclv[str(S)]], f)
+        np.random.seed(params["seed_sweep"])
+        with np.errstate(all="ignore"):
+            run_reference_script("get_BR_with_approx_sort.py", root,
+                                 [(r"^root_directory = r'.*'$", "root_directory = r'%s'" % root),
+                                  (r"^nb_CV_iterations = 30$", "nb_CV_iterations = 5")])
+        out = {}
+        for cv in range(1, 5):
+            with open(res_a + "\\BRs_S_3_BP_50_CV_%d.pkl" % cv, "rb") as f:
+                r = pickle.load(f)  # written a moment ago by the reference script run above
+            brs = r["stored_all_var_BRs"]
+            out["BRs_CV%d" % cv] = np.array(brs[len(brs) - 1][6 - 2], dtype=np.float64)  # :77, :93
+        np.random.seed(params["seed_draws"])
+        ref_dir = os.path.join(os.path.dirname(REF), "Analyse results")
+        src = open(os.path.join(ref_dir, "max_nb_channels_p_value_power_budget.py")).read()
+        for pat, repl in ((r"^root_directory = r'.*'$", "root_directory = r'%s'" % root),
+                          (r"^nb_random_CVs = 100000$", "nb_random_CVs = %d" % params["nb_random_CVs"])):
+            src, n = re.subn(pat, lambda _m, r=repl: r, src, count=1, flags=re.M)
+            assert n == 1, pat
+        glb = {"__name__": "__ref_script__"}
+        with contextlib.redirect_stdout(io.StringIO()):
+            exec(compile(src, "max_nb_channels_p_value_power_budget.py", "exec"), glb)
+        out["x"] = np.asarray(glb["x"], dtype=np.float64)
+        out["exceed"] = np.sum(glb["nb_channels_that_exceeded_power_budget"], axis=0).astype(np.int64)
+        out["raw_power"] = np.asarray(glb["raw_MUA_channels_power"], dtype=np.float64)
+        out["nb_channels_vec"] = np.asarray(glb["nb_channels_vec"], dtype=np.int64)
+        out["total_power_budget"] = np.array([glb["total_power_budget"]], dtype=np.float64)
+        out["params"] = np.frombuffer(json.dumps(params).encode(), dtype=np.uint8)
+        assert 0 < out["exceed"].sum() < out["x"].size, "fixture should straddle the budget"
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pack_dataset(d):
     """nested list of uint8 arrays -> flat arrays for npz (no pickling)."""
     flat, shape = [], []
@@ -265,6 +342,7 @@ def main():
     with open(os.path.join(OUT, "chosen_system.json"), "w") as f:
         json.dump({"BR_hex": [float(v).hex() for v in chosen], "BR": [repr(v) for v in chosen],
                    "printed": line}, f)
+    np.savez_compressed(os.path.join(OUT, "power_budget.npz"), **power_budget(tb["sclv"]))
     print("wrote", sorted(os.listdir(OUT)))
 
 

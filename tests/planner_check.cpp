@@ -1,0 +1,107 @@
+// planner_check.cpp -- runs the product's host planner (csrc/mh_planner.hpp, the code mh_plan_create
+// executes before its uploads) as a plain host program, so that it can be built with
+// -fsanitize=address,undefined.  Reads cases from stdin:
+//     C S h mode window K seg_chunks  len[0..C)  sclv[0..K*S)
+// checks the planner's internal invariants and prints, per case, the directory for the test to
+// compare with the CPU oracle's:  "nseg cap seg_chunks wave_tasks" then four lines ch / first / n / off.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "mh_planner.hpp"
+
+#define CHECK(cond)                                                    \
+    do {                                                               \
+        if (!(cond)) {                                                 \
+            fprintf(stderr, "invariant failed: %s (line %d)\n", #cond, __LINE__); \
+            return 2;                                                  \
+        }                                                              \
+    } while (0)
+
+int main()
+{
+    unsigned C, S, h, mode, window, K, sc;
+    while (scanf("%u %u %u %u %u %u %u", &C, &S, &h, &mode, &window, &K, &sc) == 7) {
+        std::vector<uint64_t> len(C), off(C);
+        std::vector<uint8_t> sclv((size_t)K * S);
+        uint64_t o = 0;
+        for (unsigned c = 0; c < C; ++c) {
+            unsigned long long v;
+            if (scanf("%llu", &v) != 1) return 1;
+            len[c] = v;
+            off[c] = o;
+            o += (v + 15) & ~15ull;
+        }
+        for (auto &b : sclv) {
+            unsigned v;
+            if (scanf("%u", &v) != 1) return 1;
+            b = (uint8_t)v;
+        }
+        const char *msg = "";
+        uint32_t arg = 0, maxlen = 0;
+        const int rc = mh::plan_check_args(len.data(), C, S, h, mode, window, sclv.data(), K, &maxlen, &msg, &arg);
+        if (rc != MH_OK) {
+            printf("error %d\n", rc);
+            continue;
+        }
+        mh::PlanHost p;
+        p.info.C = C; p.info.S = S; p.info.h = h; p.info.mode = mode; p.info.window = window;
+        p.info.K = K; p.info.seg_chunks = sc; p.info.maxlen = maxlen;
+        mh::plan_host_build(p, off.data(), len.data(), sclv.data());
+        const size_t n = p.seg_ch.size();
+        CHECK(p.info.n_segments == n && p.seg_first.size() == n && p.seg_n.size() == n && p.seg_off.size() == n);
+        // segments tile every window exactly, in order; slots do not overlap and fit the capacity
+        uint64_t samples = 0;
+        for (size_t s = 0; s < n; ++s) {
+            const uint32_t c = p.seg_ch[s];
+            CHECK(c < C && p.seg_n[s] > 0 && p.seg_n[s] <= (uint64_t)p.info.seg_chunks * MH_CHUNK);
+            CHECK(p.seg_first[s] + p.seg_n[s] <= p.w1[c] - p.w0[c]);
+            if (s + 1 < n) CHECK(p.seg_off[s] + mh::slot_words(p.seg_n[s], maxlen) == p.seg_off[s + 1]);
+            CHECK(p.seg_off[s] % 32 == 0);
+            samples += p.seg_n[s];
+        }
+        CHECK(samples == p.info.window_samples);
+        if (n) CHECK(p.seg_off[n - 1] + mh::slot_words(p.seg_n[n - 1], maxlen) + 4 == p.info.payload_cap_words);
+        // shared-table tasks: every segment once, <= 4 consecutive ones of one channel
+        size_t covered = 0;
+        for (size_t t = 0; t < p.task_seg0.size(); ++t) {
+            CHECK(p.task_seg0[t] == covered && p.task_n[t] >= 1 && p.task_n[t] <= 4);
+            for (unsigned k = 1; k < p.task_n[t]; ++k) CHECK(p.seg_ch[covered + k] == p.seg_ch[covered]);
+            covered += p.task_n[t];
+        }
+        CHECK(covered == n);
+        if (p.use_wave_tasks) {  // a permutation of the segments, longest first
+            CHECK(p.wave_seg.size() == n);
+            std::vector<uint8_t> seen(n, 0);
+            for (size_t i = 0; i < n; ++i) {
+                CHECK(p.wave_seg[i] < n && !seen[p.wave_seg[i]]);
+                seen[p.wave_seg[i]] = 1;
+                if (i) CHECK(p.seg_n[p.wave_seg[i - 1]] >= p.seg_n[p.wave_seg[i]]);
+            }
+        }
+        // histogram tiles cover the windows; calibration tiles cover min(2^h, T) when it is long
+        uint64_t tiled = 0;
+        for (size_t t = 0; t < p.tile_ch.size(); ++t) {
+            CHECK(p.tile_n[t] > 0 && p.tile_n[t] <= mh::kHistTileBytes);
+            CHECK(p.tile_start[t] + p.tile_n[t] <= p.w1[p.tile_ch[t]]);
+            tiled += p.tile_n[t];
+        }
+        CHECK(tiled == p.info.window_samples);
+        uint64_t cal = 0, cal_want = 0;
+        for (size_t t = 0; t < p.cal_tile_ch.size(); ++t) cal += p.cal_tile_n[t];
+        if (((uint64_t)1 << h) > mh::kCalDirect)
+            for (unsigned c = 0; c < C; ++c) cal_want += len[c] < ((uint64_t)1 << h) ? len[c] : ((uint64_t)1 << h);
+        CHECK(cal == cal_want);
+        CHECK(p.W >= maxlen && p.W <= 12 && (p.dec_K == 2 || p.dec_K == 4));
+        printf("%zu %llu %u %d\n", n, (unsigned long long)p.info.payload_cap_words, p.info.seg_chunks, (int)p.use_wave_tasks);
+        for (size_t s = 0; s < n; ++s) printf("%u ", p.seg_ch[s]);
+        printf("\n");
+        for (size_t s = 0; s < n; ++s) printf("%llu ", (unsigned long long)p.seg_first[s]);
+        printf("\n");
+        for (size_t s = 0; s < n; ++s) printf("%llu ", (unsigned long long)p.seg_n[s]);
+        printf("\n");
+        for (size_t s = 0; s < n; ++s) printf("%llu ", (unsigned long long)p.seg_off[s]);
+        printf("\n");
+    }
+    return 0;
+}

@@ -256,9 +256,24 @@ def test_synth_matches_oracle(mh):
         assert abs(float(cs.channel(c).float().mean()) - rates[c]) < 0.05 * max(1.0, rates[c])
 
 
+def test_rebin_dropin_equals_reference_run_fixture(mh):
+    """functions_1.bin_MUA_data (GPU) against the outputs of the reference's own function, recorded
+    in tests/golden/tables.json by oracle/make_golden.py -- uint8 counts and wide integer counts."""
+    for case in helpers.tables()["bin_MUA"]:
+        T, C, r = case["T"], case["C"], case["r"]
+        MUA = np.array(case["MUA"], np.uint8 if case["dtype"] == "uint8" else np.int64).reshape(T, C)
+        got = mh.functions_1.bin_MUA_data(MUA, r)
+        want = np.array(case["out"], np.int64).reshape(-1, C)
+        assert got.shape == want.shape and got.dtype == np.dtype(int) and np.array_equal(got, want), (T, C, r)
+    with pytest.raises(IndexError):
+        mh.functions_1.bin_MUA_data(np.zeros((10, 1), np.uint8), 5)  # the reference indexes MUA[:,1]
+    with pytest.raises(TypeError):
+        mh.functions_1.bin_MUA_data(np.zeros((10, 2)), 5)
+
+
 def test_rebin_dropin_matches_reference_semantics(mh):
     rng = np.random.RandomState(9)
-    for T, C, r in ((1000, 3, 5), (1001, 2, 10), (7, 4, 50), (4096, 1, 1)):
+    for T, C, r in ((1000, 3, 5), (1001, 2, 10), (7, 4, 50), (4096, 2, 1)):
         MUA = rng.randint(0, 60, size=(T, C)).astype(np.uint8)
         got = mh.functions_1.bin_MUA_data(MUA, r)
         nb = -(-T // r)
@@ -610,7 +625,7 @@ def test_error_paths_with_a_device(mh):
     rc = lib.mh_encode(plan._h, None, ptr(e.payload), plan.payload_cap_words, ptr(e.seg_words), ptr(e.ch_bits),
                        None, None, None, None)
     assert rc == L.ERR_ARG
-    rc = lib.mh_decode(plan._h, ptr(e.payload), None, None, None, ptr(cs.data), None)
+    rc = lib.mh_decode(plan._h, ptr(e.payload), e.payload.numel(), None, None, None, ptr(cs.data), None)
     assert rc == L.ERR_ARG
     rc = lib.mh_rebin(ptr(cs.data), ptr(cs.data), ptr(cs.data), 4, 50000, 5000, 1, ptr(cs.data), ptr(cs.data), None)
     assert rc == L.ERR_ARG and b"4096" in lib.mh_last_error()
@@ -639,7 +654,7 @@ def test_random_access_decompress_of_selected_channels(mh):
     cs = _cs(mh, chans)
     for S, h, mode, window in ((3, 6, 1, 0), (5, 6, 1, 2), (10, 3, 0, 1), (4, 8, 1, 3)):
         c = cio.compress(cs, S, h, mode, helpers.sclv_tables()[S], window=window)
-        assert int(cio.segments_per_channel(c.ch_len, h, window, 2).sum()) == len(c.seg_words)
+        assert int(cio.segments_per_channel(c.ch_len, h, window, c.header["seg_chunks"]).sum()) == len(c.seg_words)
         full = cio.decompress(c).to_channels()
         for sel in ([1], [8, 0, 5], [9, 2, 7, 6, 4, 3], list(range(10))[::-1], []):
             got = cio.decompress(c, channels=sel).to_channels()
@@ -747,7 +762,87 @@ def test_plan_parameter_grid_is_accepted_or_rejected_cleanly(mh):
         en, sk = torch.zeros_like(pk), torch.zeros_like(pk)
         L.check(lib.mh_measure(plan, p_(data), None, None, None, None, None, p_(chb), None, None))
         L.check(lib.mh_encode(plan, p_(data), p_(pay), pay.numel(), p_(segw), p_(chb), p_(pk), p_(en), p_(sk), None))
-        L.check(lib.mh_decode(plan, p_(pay), None, p_(pk), p_(en), p_(out), None))
+        L.check(lib.mh_decode(plan, p_(pay), pay.numel(), None, p_(pk), p_(en), p_(out), None))
         torch.cuda.synchronize()
         lib.mh_plan_destroy(plan)
     assert accepted > 50
+
+
+@pytest.mark.parametrize("S,h", [(3, 6), (5, 6), (10, 4)])
+def test_short_channels_training_set_shape(mh, S, h):
+    """The reference's real shape: 50 ms bins give 2e4-7e4 samples per channel and the training set
+    holds ~2400 channels (Data/get_all_binned_data.py:16, get_BR_with_approx_sort.py:24,89-90).
+    2400 channels x 72 000 bins: the planner picks one-chunk segments and the per-wave-table
+    kernels (segments of four different channels per workgroup, longest first); measure / encode /
+    decode byte-exact against the oracle."""
+    C, T = 2400, 72_000
+    tab = helpers.sclv_tables()[S]
+    cs = mh.synth.generate(C, T, seed=5)
+    host = cs.data.cpu().numpy()
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, mh.MODE_APPROX, mh.WIN_AFTER_CAL, tab)
+    assert plan.seg_chunks == 1 and plan.n_segments == C * 5
+    p = OC.Params(S, h, 1, OC.WIN_AFTER_CAL, tab, seg_chunks=plan.seg_chunks)
+    e = plan.encode(cs.data)
+    oe = OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+    sw = e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments]
+    assert np.array_equal(sw, oe["seg_words"])
+    assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+    seg = plan.segments()
+    assert np.array_equal(seg["off"], oe["seg"]["off"])
+    pay = e.payload.cpu().numpy().view(np.uint32)
+    from tests import standins
+    assert np.array_equal(standins.dense_words(pay, seg["off"], sw), standins.dense_words(oe["payload"], seg["off"], sw))
+    out = torch.zeros_like(cs.data)
+    plan.decode(e, out)
+    assert plan.decode_ok()
+    want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host), nthreads=8)
+    assert np.array_equal(out.cpu().numpy(), want)
+    m = plan.measure(cs.data)
+    assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+    plan.close()
+
+
+def test_decoder_never_reads_outside_an_untrusted_payload(mh):
+    """mh_decode on garbage: random words, a truncated stream, headers that claim huge chunks, a
+    wild segment offset table and out-of-range (peak, encoder) words.  Every launch must finish
+    without a fault; decode_ok() reports whether a segment had to be abandoned; a later decode of
+    the intact stream on the same plan is exact again."""
+    rng = np.random.RandomState(41)
+    lens = [70001, 16384 * 3 + 17, 40000, 5, 200000, 16384]
+    chans = _channels(rng, lens, 0.2, 3.0)
+    cs = _cs(mh, chans)
+    for S in (3, 5, 10):
+        tab = helpers.sclv_tables()[S]
+        for sc in (1, 2):
+            plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, mh.WIN_AFTER_CAL, tab, seg_chunks=sc)
+            e = plan.encode(cs.data)
+            good = torch.zeros_like(cs.data)
+            plan.decode(e, good)
+            assert plan.decode_ok()
+            d, tot = plan.compact(e)
+            total = int(tot.item())
+            out = torch.zeros_like(cs.data)
+            # (1) the dense stream cut short: the tail segments run out of words
+            cut = mh.codec.Encoded(d.payload[:total // 2].clone(), d.seg_words, d.ch_bits, d.peak, d.enc, d.skipped, d.seg_off, True)
+            plan.decode(cut, out)
+            assert not plan.decode_ok()
+            # (2) random words
+            junk = torch.from_numpy(rng.randint(0, 2 ** 31, size=total + 4).astype(np.int32)).cuda()
+            plan.decode(mh.codec.Encoded(junk, d.seg_words, d.ch_bits, d.peak, d.enc, d.skipped, d.seg_off, True), out)
+            plan.decode_ok()
+            # (3) every header word claims the longest possible sub-streams
+            big = d.payload.clone()
+            big[::7] = 0x7FFFFFFF
+            plan.decode(mh.codec.Encoded(big, d.seg_words, d.ch_bits, d.peak, d.enc, d.skipped, d.seg_off, True), out)
+            plan.decode_ok()
+            # (4) segment offsets far outside the buffer, (peak, encoder) words out of range
+            wild = torch.full_like(d.seg_off, 2 ** 40)
+            pk = torch.full_like(d.peak, 200)
+            plan.decode(mh.codec.Encoded(d.payload, d.seg_words, d.ch_bits, pk, pk, d.skipped, wild, True), out)
+            assert not plan.decode_ok()
+            torch.cuda.synchronize()
+            # the plan still decodes the intact stream exactly
+            out.zero_()
+            plan.decode(d, out)
+            assert plan.decode_ok() and torch.equal(out, good)
+            plan.close()

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     raw = ct.CDLL(_lib.SO)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib().mh_version() == 101
+    assert _lib.lib().mh_version() == 102
 
 
 def test_geometry_constants_match_header():
@@ -133,28 +133,15 @@ def test_container_file_roundtrip_without_gpu(tmp_path):
         cio.read(__import__("io").BytesIO(b"NOTMAGIC" + b"\0" * 16))
 
 
-def test_design_point_table_matches_reference_formula():
-    from muahuff import analysis
-    z, params = helpers.sweep()
-    res = {}
-    for key in z.files:
-        if key.startswith("approx/") and key.endswith("/BRs"):
-            S, BP, cv = [int(t[1:] if t[0] == "S" else t[2:]) for t in key.split("/")[1].split("_")]
-            res[(S, BP, cv)] = {"stored_all_var_BRs": z[key]}
-    tab = analysis.design_point_table(res)
-    # first row: BP=10, S=2, hist 2^2, 1 encoder, mean over channels and CVs (nan if any nan)
-    a = np.mean([np.mean(z["approx/S2_BP10_CV%d/BRs" % cv][0][0]) for cv in (1, 2)])
-    assert tab[0, :4].tolist() == [10, 2, 2, 1] and helpers.same_float(tab[0, 4], a)
-    assert tab.shape[1] == 6 and tab.shape[0] == 2 * 94 * 9
-
-
 def test_missing_library_fails_loudly(tmp_path):
     """No libmuahuff.so -> ImportError at first use, never a silent CPU path."""
     import subprocess
     import sys
     code = ("import muahuff\n"
-            "try:\n    muahuff._lib.lib()\nexcept ImportError as e:\n    print('LOUD', 'no CPU fallback' in str(e))\n")
-    env = dict(os.environ, MUAHUFF_LIB=str(tmp_path / "nope.so"), PYTHONPATH=ROOT)
+            "muahuff._lib.use_library(%r)\n"
+            "try:\n    muahuff._lib.lib()\nexcept ImportError as e:\n    print('LOUD', 'no CPU fallback' in str(e))\n"
+            % str(tmp_path / "nope.so"))
+    env = dict(os.environ, PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert "LOUD True" in out.stdout, out.stdout + out.stderr
 
@@ -170,3 +157,139 @@ def test_plain_c_client_builds_and_fails_loudly_without_gpu():
         pytest.skip("GPU present: covered by the gpu test")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "no HIP device" in r.stderr, r.stderr
+
+
+def test_production_library_has_no_debug_surface():
+    """No ablation hook, no environment knobs in the shipped .so (they exist only in -DMH_TUNING builds)."""
+    raw = ct.CDLL(_lib.SO)
+    assert not hasattr(raw, "mhdbg_set_ablation")
+    blob = open(_lib.SO, "rb").read()
+    for name in (b"MH_DEC_W", b"MH_DEC_NR", b"MH_DEC_RELOAD", b"MH_WAVE_TASKS", b"MUAHUFF_LIB"):
+        assert name not in blob, name
+    assert "os.environ" not in open(os.path.join(ROOT, "hardware-efficient-mua-compression_amd", "_lib.py")).read()
+
+
+def test_sclv_directory_reader_executes_nothing(tmp_path):
+    """load_directory reads reference-shaped Stored_SCLVs_S_<S>.pkl files with a pickle DISASSEMBLER:
+    a file whose unpickling would run code is read (or rejected) without running it."""
+    import pickle
+    for S in (3, 5):
+        with open(tmp_path / ("Stored_SCLVs_S_%d.pkl" % S), "wb") as f:
+            pickle.dump([np.array(r, dtype=np.float64) for r in sclv.table(S)], f)
+    got = sclv.load_directory(str(tmp_path))
+    assert sorted(got) == [3, 5] and np.array_equal(got[5], sclv.table(5))
+
+    class Boom:
+        def __reduce__(self):
+            return (os.system, ("touch %s" % (tmp_path / "pwned"),))
+    with open(tmp_path / "Stored_SCLVs_S_4.pkl", "wb") as f:
+        pickle.dump([Boom()], f)
+    with pytest.raises(ValueError):
+        sclv.load_directory(str(tmp_path))
+    assert not (tmp_path / "pwned").exists()
+
+
+def test_bin_MUA_fixture_pins_the_oracle_rebin():
+    """oracle rebin_u32 == the reference's bin_MUA_data run in the survey container (uint8 cases)."""
+    import oracle
+    for case in helpers.tables()["bin_MUA"]:
+        if case["dtype"] != "uint8":
+            continue
+        T, C, r = case["T"], case["C"], case["r"]
+        MUA = np.array(case["MUA"], np.uint8).reshape(T, C)
+        want = np.array(case["out"], np.int64).reshape(-1, C)
+        for c in range(C):
+            assert np.array_equal(oracle.c.rebin_u32(MUA[:, c].copy(), r).astype(np.int64), want[:, c]), (T, C, r, c)
+            assert np.array_equal(oracle.c.rebin_u8(MUA[:, c].copy(), r), np.minimum(want[:, c], 255).astype(np.uint8))
+
+
+def _plan_query(ch_len, S, h, mode, window, tab, seg_chunks):
+    ch_len = np.ascontiguousarray(ch_len, np.uint64)
+    tab = np.ascontiguousarray(tab, np.uint8)
+    info = _lib.PlanInfo()
+    cap = 1 << 16
+    seg = dict(ch=np.zeros(cap, np.uint32), first=np.zeros(cap, np.uint64), n=np.zeros(cap, np.uint64),
+               off=np.zeros(cap, np.uint64))
+    rc = _lib.lib().mh_plan_query(ch_len.ctypes.data, len(ch_len), S, h, mode, window, tab.ctypes.data, len(tab), seg_chunks,
+                                  ct.byref(info), seg["ch"].ctypes.data, seg["first"].ctypes.data, seg["n"].ctypes.data,
+                                  seg["off"].ctypes.data, cap)
+    return rc, info, {k: v[:int(info.n_segments)] for k, v in seg.items()}
+
+
+def test_host_planner_matches_the_oracle_directory_without_a_device():
+    """mh_plan_query is the planner of mh_plan_create minus the uploads: runs with no GPU."""
+    import oracle
+    OC = oracle.c
+    rng = np.random.RandomState(8)
+    for it in range(60):
+        S = int(rng.randint(2, 11))
+        tab = helpers.sclv_tables()[S]
+        h, mode, window, sc = int(rng.randint(0, 14)), int(rng.randint(0, 2)), int(rng.randint(0, 4)), int(rng.randint(1, 5))
+        lens = [int(rng.choice([1, 2, 63, 64, 65, 4096, 16383, 16384, 16385, 40000, 70001, 200000])) + int(rng.randint(0, 3))
+                for _ in range(int(rng.randint(1, 9)))]
+        rc, info, seg = _plan_query(lens, S, h, mode, window, tab, sc)
+        assert rc == 0
+        want = OC.plan_segments(np.array(lens, np.uint64), OC.Params(S, h, mode, window, tab, seg_chunks=sc))
+        for k in ("ch", "first", "n", "off"):
+            assert np.array_equal(seg[k], want[k]), (it, k)
+        assert int(info.payload_cap_words) == want["cap_words"] + 4 and int(info.seg_chunks) == sc
+        assert int(info.maxlen) == int(tab.max())
+    # seg_chunks = 0: one-chunk segments for small inputs, two-chunk ones for large
+    rc, info, _ = _plan_query([72000] * 2400, 3, 6, 1, 2, helpers.sclv_tables()[3], 0)
+    assert rc == 0 and int(info.seg_chunks) == 1 and int(info.n_segments) == 2400 * 5
+    rc, info, _ = _plan_query([10_000_000] * 64, 3, 6, 1, 2, helpers.sclv_tables()[3], 0)
+    assert rc == 0 and int(info.seg_chunks) == 2
+    # argument errors come back as codes with a message, never as a crash
+    rc, _, _ = _plan_query([10, 0], 3, 6, 1, 0, helpers.sclv_tables()[3], 2)
+    assert rc == _lib.ERR_EMPTY_CHANNEL and b"channel 1" in _lib.lib().mh_last_error()
+    rc, _, _ = _plan_query([10], 11, 6, 1, 0, helpers.sclv_tables()[3], 2)
+    assert rc == _lib.ERR_ARG
+    rc, _, _ = _plan_query([10], 3, 6, 1, 0, np.array([[1, 1, 2]], np.uint8), 2)
+    assert rc == _lib.ERR_SCLV
+
+
+def _validate(lens, S, h, mode, window, tab, sc, payload, seg_words, peak, enc):
+    ch_len = np.ascontiguousarray(lens, np.uint64)
+    tab = np.ascontiguousarray(tab, np.uint8)
+    payload = np.ascontiguousarray(payload, np.uint32)
+    seg_words = np.ascontiguousarray(seg_words, np.uint64)
+    pad = payload if payload.size else np.zeros(1, np.uint32)
+    return _lib.lib().mh_validate_stream(ch_len.ctypes.data, len(ch_len), S, h, mode, window, tab.ctypes.data, len(tab), sc,
+                                         pad.ctypes.data, payload.size, seg_words.ctypes.data, seg_words.size,
+                                         np.ascontiguousarray(peak, np.uint8).ctypes.data,
+                                         np.ascontiguousarray(enc, np.uint8).ctypes.data)
+
+
+def test_validate_stream_accepts_oracle_streams_and_names_corruption():
+    """mh_validate_stream (host-only C) on streams made by the oracle: accepted as they are, rejected
+    with MH_ERR_STREAM after every kind of damage a stored file can suffer."""
+    import oracle
+    from tests import standins
+    OC = oracle.c
+    rng = np.random.RandomState(3)
+    for S, h, window, sc in ((3, 6, 2, 2), (5, 4, 0, 1), (10, 3, 3, 3)):
+        tab = helpers.sclv_tables()[S]
+        lens = [70001, 16384, 5, 40000, 16385 + 64, 100]
+        chans = [np.minimum(rng.poisson(0.7, size=T), 255).astype(np.uint8) for T in lens]
+        data, off, ln = OC.flatten(chans)
+        p = OC.Params(S, h, 1, window, tab, seg_chunks=sc)
+        e = OC.encode(data, off, ln, p)
+        dense = standins.dense_words(e["payload"], e["seg"]["off"], e["seg_words"])
+        args = (lens, S, h, 1, window, tab, sc)
+        assert _validate(*args, dense, e["seg_words"], e["peak"], e["enc"]) == 0
+        bad = dense.copy()
+        bad[0] ^= 0x3000                                   # field width of the first chunk header
+        assert _validate(*args, bad, e["seg_words"], e["peak"], e["enc"]) == _lib.ERR_STREAM
+        bad = dense.copy()
+        bad[0] = (bad[0] & ~np.uint32(0xFFF)) | np.uint32(0xFFF)   # impossible minimum length
+        assert _validate(*args, bad, e["seg_words"], e["peak"], e["enc"]) == _lib.ERR_STREAM
+        assert _validate(*args, dense[:-1], e["seg_words"], e["peak"], e["enc"]) == _lib.ERR_STREAM  # truncated
+        sw = e["seg_words"].copy()
+        sw[0] += 1
+        assert _validate(*args, dense, sw, e["peak"], e["enc"]) == _lib.ERR_STREAM
+        assert _validate(*args, dense, e["seg_words"][:-1], e["peak"], e["enc"]) == _lib.ERR_STREAM
+        pk = e["peak"].copy()
+        pk[0] = S
+        assert _validate(*args, dense, e["seg_words"], pk, e["enc"]) == _lib.ERR_STREAM
+        assert b"peak" in _lib.lib().mh_last_error()
+        assert _validate(lens[:-1] + [101], S, h, 1, window, tab, sc, dense, e["seg_words"], e["peak"], e["enc"]) in (0, _lib.ERR_STREAM)

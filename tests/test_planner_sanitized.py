@@ -1,0 +1,88 @@
+"""The product's host planner (csrc/mh_planner.hpp -- the arithmetic mh_plan_create runs before it
+touches the device) built as a host program with AddressSanitizer + UBSan and compared with the CPU
+oracle's directory.  Runs without a GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "planner_check.cpp")
+EXE = os.path.join(ROOT, "tests", "planner_check_asan")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    deps = [SRC, os.path.join(ROOT, "hardware-efficient-mua-compression_amd", "csrc", "mh_planner.hpp"),
+            os.path.join(ROOT, "include", "muahuff.h")]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-fno-omit-frame-pointer", "-Wall", "-Wextra", "-Werror",
+                               "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "hardware-efficient-mua-compression_amd", "csrc"), SRC, "-o", EXE])
+    return EXE
+
+
+def _cases():
+    rng = np.random.RandomState(17)
+    tabs = helpers.sclv_tables()
+    cases = []
+    for _ in range(40):
+        S = int(rng.randint(2, 11))
+        rows = tabs[S]
+        keep = np.sort(rng.choice(len(rows), size=int(rng.randint(1, len(rows) + 1)), replace=False))
+        lens = [int(rng.choice([1, 2, 63, 64, 65, 4095, 4097, 16383, 16384, 16385, 32768, 40000, 70001, 131072 + 5, 300000]))
+                + int(rng.randint(0, 3)) for _ in range(int(rng.randint(1, 12)))]
+        cases.append((S, int(rng.randint(0, 19)), int(rng.randint(0, 2)), int(rng.randint(0, 4)), rows[keep],
+                      int(rng.randint(0, 5)), lens))
+    # the shapes of the bench and of the BASELINE configs (1024 x 1e7, 1250 x 1e7 shard, short channels)
+    cases.append((3, 6, 1, 2, tabs[3], 2, [10_000_000] * 1024))
+    cases.append((10, 10, 1, 2, tabs[10], 0, [10_000_000] * 1250))
+    cases.append((3, 6, 1, 2, tabs[3], 0, [72_000] * 2400))
+    cases.append((5, 30, 0, 3, tabs[5], 1, [2 ** 22 + 1, 5]))
+    return cases
+
+
+def test_planner_under_asan_ubsan_matches_oracle_directory(exe):
+    cases = _cases()
+    text = []
+    for S, h, mode, window, tab, sc, lens in cases:
+        text.append("%d %d %d %d %d %d %d  %s  %s" % (len(lens), S, h, mode, window, len(tab), sc,
+                                                      " ".join(map(str, lens)), " ".join(str(int(v)) for v in tab.ravel())))
+    r = subprocess.run([exe], input="\n".join(text) + "\n", capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 5 * len(cases)
+    OC = oracle.c
+    for i, (S, h, mode, window, tab, sc, lens) in enumerate(cases):
+        nseg, cap, sc_used, wave = (int(v) for v in lines[5 * i].split())
+        if sc == 0:
+            assert sc_used in (1, 2)
+        else:
+            assert sc_used == sc
+        want = OC.plan_segments(np.array(lens, np.uint64), OC.Params(S, h, mode, window, tab, seg_chunks=sc_used))
+        assert nseg == len(want["ch"]) and cap == want["cap_words"] + 4, i
+        for k, name in enumerate(("ch", "first", "n", "off")):
+            got = np.array(lines[5 * i + 1 + k].split(), dtype=np.uint64)
+            assert np.array_equal(got, want[name].astype(np.uint64)), (i, name)
+        # slot sizes agree with the oracle's formula segment by segment
+        maxlen = int(tab.max())
+        for s in range(min(nseg, 50)):
+            nxt = int(want["off"][s + 1]) if s + 1 < nseg else cap - 4
+            assert nxt - int(want["off"][s]) == OC.slot_words(int(want["n"][s]), maxlen)
+
+
+def test_planner_rejects_bad_arguments_under_sanitizers(exe):
+    bad = ["1 3 6 1 0 1 2  0  1 2 2",        # empty channel
+           "1 11 6 1 0 1 2  5  1 2 3 4 5 6 7 8 9 9 9",  # S out of range
+           "1 3 31 1 0 1 2  5  1 2 2",       # h out of range
+           "1 3 6 1 0 1 2  5  1 1 2",        # Kraft sum != 1
+           "2 3 6 1 9 1 2  5 6  1 2 2"]      # window rule unknown
+    r = subprocess.run([exe], input="\n".join(bad) + "\n", capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["error", "-2", "error", "-1", "error", "-1", "error", "-3", "error", "-1"]

@@ -6,7 +6,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+import importlib
+
 import muahuff
+
+# the ablation hook and the env knobs exist only in the -DMH_TUNING build of the library
+muahuff._lib.use_library(importlib.import_module("hardware-efficient-mua-compression_amd.build").build(tuning=True))
 from muahuff import codec, sclv, synth
 
 C, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 10_000_000
