@@ -6,7 +6,8 @@
 //                   np.mean / np.max of a design point's per-channel bit rates
 // float64 sums follow NumPy's pairwise summation (numpy/core/src/umath/loops_utils.h.src,
 // pairwise_sum_DOUBLE: blocks of <= 128 with eight running sums, halves split at a multiple of 8),
-// written with __dadd_rn / __dmul_rn so that the compiler can neither reorder nor contract them.
+// with floating-point contraction switched OFF in every function (HIP's __dadd_rn / __dmul_rn are
+// plain operators: without the pragma hipcc fuses a*b+c into one FMA and the last bits differ).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,6 +24,7 @@ struct VecRef {
 
 __device__ inline double pairwise_block(const VecRef &a, uint64_t lo, uint64_t n)
 {
+#pragma clang fp contract(off)
     if (n < 8) {
         double res = 0.;
         for (uint64_t i = 0; i < n; ++i) res = __dadd_rn(res, a.at(lo + i));
@@ -45,6 +47,7 @@ __device__ inline double pairwise_block(const VecRef &a, uint64_t lo, uint64_t n
 // a multiple of 8 and the rest; the stack holds pending right halves and partial sums.
 __device__ inline double pairwise_sum(const VecRef &a, uint64_t n)
 {
+#pragma clang fp contract(off)
     // depth <= log2(n / 128) + 1; 48 levels cover any 64-bit n
     uint64_t lo_st[48], n_st[48];
     double acc_st[48];
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(256) void k_power_draws(const double *br, const int
                                                      double comm_energy, double per_channels, double static_power,
                                                      double *x, uint64_t x_stride)
 {
+#pragma clang fp contract(off)
     const uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (d >= n_draws) return;
     VecRef a{br, idx + d, n_draws};
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256) void k_power_draws(const double *br, const int
 __global__ __launch_bounds__(256) void k_reduce_rows(const double *vals, const uint64_t *row_off, uint64_t n_rows,
                                                      double *sum, double *mx)
 {
+#pragma clang fp contract(off)
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_rows) return;
     const uint64_t lo = row_off[r], n = row_off[r + 1] - lo;

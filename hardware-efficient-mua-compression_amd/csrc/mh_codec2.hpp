@@ -15,12 +15,14 @@
 // Partial (last) chunks of a channel go through the first-generation per-symbol routines.
 #pragma once
 #include "mh_kernels.hpp"
+#include "mh_planner.hpp"
 
 namespace mh {
 
 struct TaskArgs {
-    const uint32_t *task_seg0;  // first segment of the task
-    const uint8_t *task_n;      // segments in the task (1..4), all of one channel
+    const uint32_t *task_seg0;  // shared-table kernels: first segment of the workgroup task
+    const uint8_t *task_n;      //   segments in the task (1..4), all of one channel
+    const WaveTask *wt;         // per-wave-table kernels: one record per wave task (mh_planner.hpp)
     uint32_t ntask;
 };
 
@@ -44,9 +46,9 @@ __host__ __device__ inline uint32_t enc2_wave_dwords(uint32_t stage_dw)
 // wave prefix sum, zero the chunk image in place, then OR every codeword into it with global
 // atomics.  Correct for any data; only adversarial inputs ever get here.
 // Returns {words written, code bits}.
-__device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src, uint32_t m,
-                                                const uint2 *lut1, uint32_t *__restrict__ gdst,
-                                                int lane)
+__device__ __forceinline__ uint2 encode_chunk_slow_body(const uint8_t *__restrict__ src, uint32_t m,
+                                                        const uint2 *lut1, uint32_t *__restrict__ gdst,
+                                                        int lane)
 {
     uint32_t tot = 0;
 #pragma unroll 1
@@ -91,6 +93,16 @@ __device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src,
     }
     __threadfence();
     return make_uint2(hw + nw, B);
+}
+
+// Out of line for the full-chunk loop (keeps the hot kernel small).  The partial-chunk routine, itself
+// out of line, inlines the body instead: a call inside a callee would need a stack frame, and with
+// it scratch memory for every wave of the kernel.
+__device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src, uint32_t m,
+                                                const uint2 *lut1, uint32_t *__restrict__ gdst,
+                                                int lane)
+{
+    return encode_chunk_slow_body(src, m, lut1, gdst, lane);
 }
 
 // LC: accumulator checks.  0 maxlen<=2: one per piece; 1 maxlen<=4: one per 2 dwords (8 codewords
@@ -221,6 +233,7 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
 }
 
 // chunk whose sub-streams outgrew the staging: flush the carried tail, then the global slow path
+template <bool INLINE_SLOW>
 __device__ __forceinline__ void overflow_chunk(const uint8_t *src, uint32_t m, const uint2 *lut1, uint32_t *buf,
                                                uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
                                                uint32_t &words, uint32_t &bits)
@@ -229,7 +242,7 @@ __device__ __forceinline__ void overflow_chunk(const uint8_t *src, uint32_t m, c
     MH_WAVE_SYNC();
     dst += pend;
     pend = 0;
-    const uint2 r = encode_chunk_slow(src, m, lut1, dst, lane);
+    const uint2 r = INLINE_SLOW ? encode_chunk_slow_body(src, m, lut1, dst, lane) : encode_chunk_slow(src, m, lut1, dst, lane);
     words = r.x;
     bits = r.y;
     dst += words;
@@ -384,7 +397,7 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
     }
     MH_WAVE_SYNC();
     if (__any(sp > cap)) {
-        overflow_chunk(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
+        overflow_chunk<false>(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
         return;
     }
     merge_and_flush<(LC == 0 ? 4 : 8), ABL>(buf, cap, tot, sp, dst, pend, lane, words, bits);
@@ -450,7 +463,7 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
     }
     MH_WAVE_SYNC();
     if (__any(sp > cap))
-        overflow_chunk(src, m, lut1, buf, dst, pend, lane, words, bits);
+        overflow_chunk<true>(src, m, lut1, buf, dst, pend, lane, words, bits);
     else
         merge_and_flush<NE, 0>(buf, cap, tot, sp, dst, pend, lane, words, bits);
     return make_uint4(words, bits, pend, (uint32_t)(dst - dst0));
@@ -458,21 +471,27 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
 
 // One segment, one wave: the chunks of segment `seg` of channel `ch` through the wave's tables
 // (lut2 pair table, lut1 single-symbol table) and its staging buffer.
-template <int LC, int PB, int ABL>
-__device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, uint32_t ch, const uint2 *lut2,
+// the first kWin rows of a segment that starts with a full chunk
+__device__ __forceinline__ void load_first_rows(u32x4 (&v)[kWin], const uint8_t *src, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
+}
+
+// src = first sample, n = samples, out = the segment's slot.  PRE: the caller has already issued
+// load_first_rows into v (when n >= one chunk) -- the per-wave-table kernel does so before it builds
+// its tables, so that the rows are in flight while the table entries are computed.
+template <int LC, int PB, int ABL, bool PRE>
+__device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, uint32_t ch, const uint8_t *src, uint64_t n,
+                                               uint32_t *__restrict__ out, u32x4 (&v)[kWin], const uint2 *lut2,
                                                const uint2 *lut1, uint32_t *buf, uint32_t cap, int lane)
 {
-    const uint8_t *src = e.data + e.ch_off[ch] + e.w0[ch] + e.seg_first[seg];
-    const uint64_t n = e.seg_n[seg];
-    uint32_t *__restrict__ out = e.payload + e.seg_off[seg];  // next unflushed word
-    uint32_t pend = 0;                                        // words waiting in LDS behind `out`
+    uint32_t pend = 0;  // words waiting in LDS behind `out` (the next unflushed word)
     const uint32_t nfull = (uint32_t)(n / kChunk);
     const uint32_t rem = (uint32_t)(n % kChunk);
     uint64_t words = 0, bits = 0;
     if (nfull) {
-        u32x4 v[kWin];
-#pragma unroll
-        for (int k = 0; k < kWin; ++k) v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
+        if (!PRE) load_first_rows(v, src, lane);
         for (uint32_t c = 0; c < nfull; ++c) {
             uint32_t w, b;
             encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, lut1, buf, cap,
@@ -501,7 +520,7 @@ template <int LC, int PB, int ABL = 0>
 __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t task = blockIdx.x;
     const uint32_t seg0 = a.t.task_seg0[task];
     const uint32_t nseg = a.t.task_n[task];
@@ -523,31 +542,37 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     if ((uint32_t)wave >= nseg) return;
     const uint32_t cap = a.e.stage_dw;
     uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
-    encode_segment<LC, PB, ABL>(a.e, seg0 + wave, ch, lut2, lut1, buf, cap, lane);
+    const uint32_t seg = seg0 + (uint32_t)wave;
+    u32x4 v[kWin];
+    encode_segment<LC, PB, ABL, false>(a.e, seg, ch, a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg],
+                                       a.e.seg_n[seg], a.e.payload + a.e.seg_off[seg], v, lut2, lut1, buf, cap, lane);
 }
 
 // Short channels (the reference's real recordings at 50 ms bins are 2e4-7e4 samples per channel,
 // Data/get_all_binned_data.py:16): one WAVE per segment, any channel, with the wave's own tables,
-// so a workgroup packs segments of four different channels and no wave idles.  task_seg0[i] is the
-// segment of wave-task i (the planner orders them longest first).
+// so a workgroup packs segments of four different channels and no wave idles.  One 32-byte record
+// per wave task (the planner orders them longest first) replaces the task -> segment -> channel
+// chain of dependent loads, and the segment's first rows are requested before the tables are built.
 __host__ __device__ inline uint32_t enc2w_wave_dwords(uint32_t stage_dw) { return kEncSharedDw + enc2_wave_dwords(stage_dw); }
 
 template <int LC, int PB>
 __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t slot = blockIdx.x * 4 + (uint32_t)wave;
     if (slot >= a.t.ntask) return;
-    const uint32_t seg = a.t.task_seg0[slot];
-    const uint32_t ch = a.e.seg_ch[seg];
+    const WaveTask t = a.t.wt[slot];
     const uint32_t cap = a.e.stage_dw;
     uint32_t *wbase = smem + (size_t)wave * enc2w_wave_dwords(cap);
     uint2 *lut2 = reinterpret_cast<uint2 *>(wbase);
     uint2 *lut1 = reinterpret_cast<uint2 *>(wbase + 512);
+    const uint8_t *src = a.e.data + t.src_off;
+    u32x4 v[kWin];
     {
-        const uint2 *g = a.e.lut + (size_t)ch * kLut;
+        const uint2 *g = a.e.lut + (size_t)t.ch * kLut;
         const uint2 el = lane < kLut ? g[lane] : make_uint2(0u, 0u);  // the 16 single-symbol entries, one per lane
+        if (t.n >= (uint32_t)kChunk) load_first_rows(v, src, lane);   // in flight during the table build
         constexpr uint32_t m = (1u << PB) - 1u;
 #pragma unroll
         for (uint32_t t0 = 0; t0 < (1u << (2 * PB)); t0 += 64) {
@@ -561,7 +586,8 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
         if (lane < kLut) lut1[lane] = el;
     }
     MH_WAVE_SYNC();
-    encode_segment<LC, PB, 0>(a.e, seg, ch, lut2, lut1, wbase + kEncSharedDw, cap, lane);
+    encode_segment<LC, PB, 0, true>(a.e, t.seg, t.ch, src, t.n, a.e.payload + t.dst_off, v, lut2, lut1,
+                                    wbase + kEncSharedDw, cap, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -575,7 +601,6 @@ struct Dtab2Args {
     void *dtab2;  // K == 4 plans only: C << W entries uint2 {4 symbol bytes, bits consumed}
     uint8_t *dtab;  // C*512 per-symbol table: symbol | len << 4, indexed by the next maxlen bits
     uint8_t *dlen;  // C : max code length of the channel's encoder
-    uint32_t *err;  // decode status word, cleared here (this kernel precedes every decode launch)
 };
 
 // Per-symbol table of every channel, and for K == 4 plans (maxlen <= 2) the 4-symbol table:
@@ -585,7 +610,6 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
 {
     const uint32_t ch = blockIdx.x;
     const int S = (int)a.S, W = (int)a.W, K = (int)a.K;
-    if (ch == 0 && threadIdx.x == 0) *a.err = 0;
     // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
     const int p = a.peak[ch] < S ? a.peak[ch] : 0;
     const uint32_t k = a.enc[ch] < a.nK ? a.enc[ch] : 0;
@@ -628,6 +652,11 @@ struct Dec2Args {
     TaskArgs t;
     const void *dtab2;
     uint32_t W;  // table index bits
+    // per-wave-table kernel: builds its tables itself from the (peak, encoder) word
+    const uint8_t *peak, *enc;
+    const uint32_t *codes;
+    uint32_t S, mode, nK;
+    uint32_t plan_slots;  // 1: segments sit in the plan's slots (offset in the task record)
 };
 
 // LDS dwords of the workgroup-shared tables: multi-symbol table (2 dwords per entry for K = 4,
@@ -652,8 +681,10 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw32, int lane)
     const uint32_t incl = wave_scan_incl(len, lane);
     ChunkHdr h;
     h.P = incl - len;
-    h.nw = (__shfl(incl, 63, 64) + 31) >> 5;
-    h.hw = hdr_words(wid);
+    // chunk sizes are wave-uniform: keep them in scalar registers (the stream pointers and the
+    // bounds checks derived from them then cost no vector registers)
+    h.nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)((__shfl(incl, 63, 64) + 31) >> 5));
+    h.hw = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr_words(wid));
     return h;
 }
 
@@ -800,14 +831,14 @@ template <int K, int M, int RL, bool HY>
 __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict__ in, uint32_t m, const uint32_t *tabw,
                                                   uint32_t tbase, uint32_t maskW, const uint8_t *tab1, uint32_t mask1,
                                                   uint32_t *stage, uint32_t cap_words, uint8_t *__restrict__ out,
-                                                  int lane, uint64_t avail, uint32_t *err)
+                                                  int lane, uint64_t avail, uint32_t *err, uint32_t epoch)
 {
     // avail = words readable from `in` on; the chunk's header, payload and 3 words of read-ahead
     // must lie inside, else the chunk is abandoned (corrupt or truncated stream)
-    if (avail < 1) { if (lane == 0) atomicOr(err, 1u); return; }
+    if (avail < 1) { if (lane == 0) atomicMax(err, epoch); return; }
     const uint32_t w0 = in[0];
     const uint32_t mn = w0 & 0xFFFu, hwid = (w0 >> 12) & 15u;
-    if (avail < hdr_words(hwid)) { if (lane == 0) atomicOr(err, 1u); return; }
+    if (avail < hdr_words(hwid)) { if (lane == 0) atomicMax(err, epoch); return; }
     uint32_t len = mn;
     if (hwid) {
         const uint32_t fb = 16u + (uint32_t)lane * hwid;
@@ -821,7 +852,7 @@ __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict_
     h.nw = (__shfl(incl, 63, 64) + 31) >> 5;
     h.hw = hdr_words(hwid);
     const uint32_t ns = h.nw + 3;
-    if (avail < (uint64_t)h.hw + ns) { if (lane == 0) atomicOr(err, 1u); return; }
+    if (avail < (uint64_t)h.hw + ns) { if (lane == 0) atomicMax(err, epoch); return; }
     if (ns > cap_words) {
         decode_chunk<3, false>(in, m, tab1, mask1, out, lane);
         return;
@@ -846,9 +877,9 @@ __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict_
 // One segment, one wave: the chunks of segment `seg` through the wave's tables (`tab` multi-symbol
 // table at LDS byte address `tbase`, `tab1` per-symbol table) and its payload staging area.
 template <int K, int M, int NR, int RL, bool HY>
-__device__ __forceinline__ void decode_segment(const DecArgs &d, uint32_t seg, uint32_t ch, const uint32_t *tab,
-                                               uint32_t tbase, uint32_t maskW, const uint8_t *tab1, uint32_t mask1,
-                                               uint32_t *stage, int lane)
+__device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, uint8_t *__restrict__ out, uint64_t n,
+                                               const uint32_t *tab, uint32_t tbase, uint32_t maskW, const uint8_t *tab1,
+                                               uint32_t mask1, uint32_t *stage, int lane)
 {
     constexpr uint32_t kCap = NR * 64;
     // Untrusted input: `pos` = word index of the chunk being entered, `lim` = words that may be
@@ -857,10 +888,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint32_t seg, u
     // chunk's first 32 words where there is one) lie below lim; otherwise the segment is abandoned
     // and *err set.  Stores only ever go to the plan's own window positions.
     const uint64_t lim = d.payload_words;
-    uint64_t pos = d.seg_off[seg];
     const uint32_t *in = d.payload + pos;
-    uint8_t *out = d.out + d.ch_off[ch] + d.w0[ch] + d.seg_first[seg];
-    const uint64_t n = d.seg_n[seg];
     const uint32_t nfull = (uint32_t)(n / kChunk);
     const uint32_t rem = (uint32_t)(n % kChunk);
 #define MH_DEC_BAIL()                              \
@@ -919,7 +947,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint32_t seg, u
     }
     if (rem)
         decode_partial_chunk<K, M, RL, HY>(in, rem, tab, tbase, maskW, tab1, mask1, stage, kCap, out + (size_t)nfull * kChunk,
-                                            lane, pos < lim ? lim - pos : 0, d.err);
+                                            lane, pos < lim ? lim - pos : 0, d.err, d.epoch);
 #undef MH_DEC_BAIL
 }
 
@@ -938,7 +966,7 @@ template <int K, int M, int NR, int RL, bool HY>
 __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t task = blockIdx.x;
     const uint32_t seg0 = a.t.task_seg0[task];
     const uint32_t nseg = a.t.task_n[task];
@@ -971,34 +999,73 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
     __syncthreads();
     if ((uint32_t)wave >= nseg) return;
     uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * (NR * 64);
-    decode_segment<K, M, NR, RL, HY>(a.d, seg0 + wave, ch, tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
+    const uint32_t seg = seg0 + (uint32_t)wave;
+    decode_segment<K, M, NR, RL, HY>(a.d, a.d.seg_off[seg], a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg],
+                                     a.d.seg_n[seg], tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
 }
 
-// Short channels: one WAVE per segment of any channel, tables per wave (see k_encode2w).
+// Short channels: one WAVE per segment of any channel, tables per wave (see k_encode2w).  The wave
+// derives its tables from the channel's (peak, encoder) word and the plan's codebooks itself, so
+// this decode is ONE launch: no table kernel in front of it.
 template <int K, int M, int NR, int RL, bool HY>
 __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t slot = blockIdx.x * 4 + (uint32_t)wave;
     if (slot >= a.t.ntask) return;
-    const uint32_t seg = a.t.task_seg0[slot];
-    const uint32_t ch = a.d.seg_ch[seg];
+    const WaveTask t = a.t.wt[slot];
     const uint32_t W = a.W;
+    const int S = (int)a.S;
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;
     const uint32_t wdw = dec2_shared_dwords(W, K) + NR * 64;  // dwords per wave
     uint32_t *tab = smem + (size_t)wave * wdw;
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (kEntDw << W));
-    const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
-    {
-        const uint32_t *g1 = reinterpret_cast<const uint32_t *>(a.d.dtab + (size_t)ch * kDtab);
-        uint32_t *t1 = reinterpret_cast<uint32_t *>(tab1);
-        t1[lane] = g1[lane];
-        t1[lane + 64] = g1[lane + 64];
+    const uint64_t pos = a.plan_slots ? t.dst_off : a.d.seg_off[t.seg];
+    // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
+    const int p = a.peak[t.ch] < S ? a.peak[t.ch] : 0;
+    const uint32_t k = a.enc[t.ch] < a.nK ? a.enc[t.ch] : 0;
+    // rank r of the channel's code: bit-reversed code | len << 16 | symbol << 24, one rank per lane
+    uint32_t mine = 0;
+    if (lane < S) mine = a.codes[k * 16 + lane] | ((uint32_t)symbol_of_rank((int)a.mode, S, p, lane) << 24);
+    uint32_t rk[MH_LUT_SYMS];
+#pragma unroll
+    for (int r = 0; r < MH_LUT_SYMS; ++r) rk[r] = __shfl(mine, r, 64);
+    uint32_t L = 0;  // rows are non-decreasing: the last rank has the longest code
+#pragma unroll
+    for (int r = 0; r < MH_LUT_SYMS; ++r)
+        if (r == S - 1) L = (rk[r] >> 16) & 0xFFu;
+    const uint32_t mask1 = (1u << L) - 1u;
+    for (uint32_t j = lane; j < (1u << L); j += 64) {  // per-symbol table: symbol | len << 4
+        uint32_t e = 0;
+#pragma unroll
+        for (int r = 0; r < MH_LUT_SYMS; ++r)
+            if (r < S) {
+                const uint32_t l = (rk[r] >> 16) & 0xFFu;
+                if ((j & ((1u << l) - 1u)) == (rk[r] & 0xFFFFu)) e = (rk[r] >> 24) | (l << 4);
+            }
+        tab1[j] = (uint8_t)e;
     }
-    if (K == 4) {
-        const uint32_t *g = reinterpret_cast<const uint32_t *>(a.dtab2) + (((size_t)ch << W) * kEntDw);
-        for (uint32_t i = lane; i < (kEntDw << W); i += 64) tab[i] = g[i];
+    if (K == 4) {  // the next W = 8 bits always hold 4 whole codewords -> {symbols spread to bytes, bits}
+        for (uint32_t idx = lane; idx < (1u << W); idx += 64) {
+            uint32_t bpos = 0, bytes = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hit_sym = 0, hit_len = 0;
+#pragma unroll
+                for (int r = 0; r < MH_LUT_SYMS; ++r)
+                    if (r < S) {
+                        const uint32_t l = (rk[r] >> 16) & 0xFFu;
+                        if (((idx >> bpos) & ((1u << l) - 1u)) == (rk[r] & 0xFFFFu)) {
+                            hit_sym = rk[r] >> 24;
+                            hit_len = l;
+                        }
+                    }
+                bytes |= hit_sym << (8 * j);
+                bpos += hit_len;
+            }
+            reinterpret_cast<uint2 *>(tab)[idx] = make_uint2(bytes, bpos);
+        }
     } else {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1014,7 +1081,7 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tab;
-    decode_segment<K, M, NR, RL, HY>(a.d, seg, ch, tab, tbase, (1u << W) - 1u, tab1, mask1,
+    decode_segment<K, M, NR, RL, HY>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
                                      tab + dec2_shared_dwords(W, K), lane);
 }
 

@@ -303,9 +303,11 @@ struct DecArgs {
     uint8_t *out;
     uint32_t nseg;
     // every read of the stream stays below payload + payload_words whatever the stream holds; a
-    // segment whose headers point outside is abandoned and *err is set
+    // segment whose headers point outside is abandoned and *err raised to this call's epoch
+    // (mh_decode_status compares; nothing has to be cleared between calls)
     uint64_t payload_words;
     uint32_t *err;
+    uint32_t epoch;
 };
 
 template <int FI, bool FULL>

@@ -62,6 +62,17 @@ inline uint64_t slot_words(uint64_t n, uint32_t maxlen)
     return (words + 31) & ~(uint64_t)31;
 }
 
+// One wave task of the per-wave-table kernels: everything the wave needs to start, in one 32-byte
+// record (one scalar load instead of the task -> segment -> channel chain of dependent loads).
+struct WaveTask {
+    uint64_t src_off;  // bytes from the data pointer to the segment's first sample
+    uint64_t dst_off;  // the segment's slot, words from the payload pointer
+    uint32_t n;        // samples
+    uint32_t ch;       // channel
+    uint32_t seg;      // directory entry
+    uint32_t pad;
+};
+
 struct PlanHost {
     mh_plan_info_t info{};
     uint64_t max_T = 0;
@@ -75,7 +86,7 @@ struct PlanHost {
     std::vector<uint32_t> task_seg0;
     std::vector<uint8_t> task_n;
     // wave tasks of the per-wave-table kernels: every segment once, longest first
-    std::vector<uint32_t> wave_seg;
+    std::vector<WaveTask> wave_tasks;
     bool use_wave_tasks = false;
     // window-histogram tiles, calibration tiles (windows above kCalDirect samples)
     std::vector<uint32_t> tile_ch, tile_n, cal_tile_ch, cal_tile_n;
@@ -204,10 +215,14 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
     p.use_wave_tasks = padded_waves * 15 > (uint64_t)I.n_segments * 16;
     if (tune.wave_tasks >= 0) p.use_wave_tasks = tune.wave_tasks != 0;
     if (p.use_wave_tasks) {
-        p.wave_seg.resize(p.seg_ch.size());
-        std::iota(p.wave_seg.begin(), p.wave_seg.end(), 0u);
-        std::stable_sort(p.wave_seg.begin(), p.wave_seg.end(),
-                         [&](uint32_t a, uint32_t b) { return p.seg_n[a] > p.seg_n[b]; });
+        std::vector<uint32_t> order(p.seg_ch.size());
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return p.seg_n[a] > p.seg_n[b]; });
+        p.wave_tasks.resize(order.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            const uint32_t s = order[i], c = p.seg_ch[s];
+            p.wave_tasks[i] = WaveTask{ch_off[c] + p.w0[c] + p.seg_first[s], p.seg_off[s], (uint32_t)p.seg_n[s], c, s, 0u};
+        }
     }
     // calibration: one wave per channel reads the window directly up to kCalDirect samples (the
     // reference's range is 2^2..2^10); longer windows go through the tiled histogram kernel

@@ -87,14 +87,15 @@ struct mh_plan {
     // segment of every wave task
     uint32_t *d_task_seg0 = nullptr;
     uint8_t *d_task_n = nullptr;
-    uint32_t *d_wave_seg = nullptr;
+    mh::WaveTask *d_wave_tasks = nullptr;
     uint64_t *d_scan = nullptr;  // block sums of mh_compact's segment scan
     // calibration windows above kCalDirect samples: tiles for the window-histogram kernel
     uint32_t *d_cal_tile_ch = nullptr, *d_cal_tile_n = nullptr;
     uint64_t *d_cal_tile_start = nullptr;
     unsigned long long *d_calhist = nullptr;
     uint2 *d_dtab2 = nullptr;  // 4-symbol decode tables (dec_K == 4 plans only)
-    uint32_t *d_err = nullptr;  // decode status word (mh_decode_status)
+    uint32_t *d_err = nullptr;  // decode status word (mh_decode_status): epoch of the last failed decode
+    uint32_t epoch = 0;         // number of mh_decode calls on this plan
 };
 
 struct mh_sweep {
@@ -342,7 +343,7 @@ int mh_plan_destroy(mh_plan *p)
     void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
-                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_seg, p->d_dtab2, p->d_scan,
+                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_dtab2, p->d_scan,
                     p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -368,9 +369,9 @@ static int plan_upload(mh_plan *p)
         (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_dtab, (size_t)C * mh::kDtab)) ||
         (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
         (rc = upload(&p->d_task_seg0, H.task_seg0)) || (rc = upload(&p->d_task_n, H.task_n)) ||
-        (H.use_wave_tasks && (rc = upload(&p->d_wave_seg, H.wave_seg))) ||
+        (H.use_wave_tasks && (rc = upload(&p->d_wave_tasks, H.wave_tasks))) ||
         (H.dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << H.W))) ||
-        (rc = alloc(&p->d_scan, H.seg_ch.size() / mh::kScanBlock + 2)) || (rc = alloc(&p->d_err, 1)) ||
+        (rc = alloc(&p->d_scan, H.seg_ch.size() / mh::kScanBlock + 2)) || (rc = upload(&p->d_err, std::vector<uint32_t>(1, 0u))) ||
         (cal && ((rc = upload(&p->d_cal_tile_ch, H.cal_tile_ch)) || (rc = upload(&p->d_cal_tile_n, H.cal_tile_n)) ||
                  (rc = upload(&p->d_cal_tile_start, H.cal_tile_start)) ||
                  (rc = alloc(&p->d_calhist, (size_t)C * mh::kHistStride)))))
@@ -519,12 +520,14 @@ static mh::TaskArgs task_args(const mh_plan *p)
 {
     mh::TaskArgs t;
     if (p->h.use_wave_tasks) {  // one wave per segment, longest first
-        t.task_seg0 = p->d_wave_seg;
+        t.task_seg0 = nullptr;
         t.task_n = nullptr;
-        t.ntask = (uint32_t)p->h.wave_seg.size();
+        t.wt = p->d_wave_tasks;
+        t.ntask = (uint32_t)p->h.wave_tasks.size();
     } else {                    // one workgroup per <= 4 consecutive segments of a channel
         t.task_seg0 = p->d_task_seg0;
         t.task_n = p->d_task_n;
+        t.wt = nullptr;
         t.ntask = (uint32_t)p->h.task_seg0.size();
     }
     return t;
@@ -613,6 +616,20 @@ int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const
     a.nseg = (uint32_t)p->h.info.n_segments;
     a.payload_words = payload_words;
     a.err = p->d_err;
+    a.epoch = ++p->epoch;
+    mh::Dec2Args a2;
+    a2.d = a;
+    a2.t = task_args(p);
+    a2.dtab2 = p->d_dtab2;
+    a2.W = p->h.W;
+    a2.peak = peak;
+    a2.enc = enc;
+    a2.codes = p->d_codes;
+    a2.S = p->h.info.S;
+    a2.mode = p->h.info.mode;
+    a2.nK = p->h.info.K;
+    a2.plan_slots = seg_off ? 0u : 1u;
+    if (p->h.use_wave_tasks) return dispatch_decode(p, a2, st);  // builds its tables itself: one launch
     mh::Dtab2Args t2;
     t2.peak = peak;
     t2.enc = enc;
@@ -627,14 +644,8 @@ int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const
     t2.dtab2 = p->d_dtab2;
     t2.dtab = p->d_dtab;
     t2.dlen = p->d_dlen;
-    t2.err = p->d_err;  // cleared here, set by a decoder wave that had to abandon a segment
     hipLaunchKernelGGL(mh::k_build_dtab2, dim3(t2.C), dim3(256), 0, st, t2);
     MH_HIP(hipGetLastError());
-    mh::Dec2Args a2;
-    a2.d = a;
-    a2.t = task_args(p);
-    a2.dtab2 = p->d_dtab2;
-    a2.W = p->h.W;
     return dispatch_decode(p, a2, st);
 }
 
@@ -642,8 +653,16 @@ int mh_decode_status(mh_plan *p, uint32_t *flags, void *stream)
 {
     if (!p || !flags) return fail(MH_ERR_ARG, "mh_decode_status: NULL argument");
     if (int rc_ = check_device(p->device, "mh_decode_status")) return rc_;
-    MH_HIP(hipMemcpyAsync(flags, p->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    uint32_t seen = 0;
+    MH_HIP(hipMemcpyAsync(&seen, p->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     MH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    // a failing decode raises the word to its epoch; replays of a captured decode reuse the epoch they
+    // were captured with, so the word is reset once it has been reported
+    *flags = (p->epoch != 0 && seen == p->epoch) ? 1u : 0u;
+    if (seen) {
+        MH_HIP(hipMemsetAsync(p->d_err, 0, sizeof(uint32_t), (hipStream_t)stream));
+        MH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    }
     return MH_OK;
 }
 

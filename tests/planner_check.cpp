@@ -70,13 +70,17 @@ int main()
             covered += p.task_n[t];
         }
         CHECK(covered == n);
-        if (p.use_wave_tasks) {  // a permutation of the segments, longest first
-            CHECK(p.wave_seg.size() == n);
+        if (p.use_wave_tasks) {  // a permutation of the segments, longest first, records consistent with the directory
+            CHECK(p.wave_tasks.size() == n);
             std::vector<uint8_t> seen(n, 0);
             for (size_t i = 0; i < n; ++i) {
-                CHECK(p.wave_seg[i] < n && !seen[p.wave_seg[i]]);
-                seen[p.wave_seg[i]] = 1;
-                if (i) CHECK(p.seg_n[p.wave_seg[i - 1]] >= p.seg_n[p.wave_seg[i]]);
+                const mh::WaveTask &t = p.wave_tasks[i];
+                CHECK(t.seg < n && !seen[t.seg]);
+                seen[t.seg] = 1;
+                CHECK(t.ch == p.seg_ch[t.seg] && t.n == p.seg_n[t.seg] && t.dst_off == p.seg_off[t.seg]);
+                CHECK(t.src_off == off[t.ch] + p.w0[t.ch] + p.seg_first[t.seg]);
+                CHECK(t.src_off + t.n <= off[t.ch] + len[t.ch]);
+                if (i) CHECK(p.wave_tasks[i - 1].n >= t.n);
             }
         }
         // histogram tiles cover the windows; calibration tiles cover min(2^h, T) when it is long

@@ -74,7 +74,12 @@ __global__ __launch_bounds__(256) void k_copy(const u32x4* __restrict__ src, u32
 }
 
 // encoder-like mix: each wave reads 16 KiB chunks and writes WOUT bytes per chunk (contiguous per
-// segment), store flavour ST: 0 plain dwordx4, 1 nontemporal dwordx4, 2 plain but batched x4 chunks
+// segment), store flavour ST: 0 plain dwordx4, 1 nontemporal dwordx4, 2 plain but batched x4 chunks,
+// 3 nontemporal batched x2 chunks (one burst per 2-chunk segment), 4 nontemporal into a LOG: the
+// wave reserves its bytes with one atomicAdd on a global cursor, so the chip writes one moving
+// front instead of per-segment slots
+__device__ unsigned long long g_cursor;
+__global__ void k_reset_cursor() { g_cursor = 0; }
 template <int ST>
 __global__ __launch_bounds__(256) void k_wave_rw(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t chunks, uint32_t wout, size_t nseg, size_t slot)
 {
@@ -97,8 +102,15 @@ __global__ __launch_bounds__(256) void k_wave_rw(const uint8_t* __restrict__ src
         }
         pending += wout;
         if (ST == 2 && (c & 3) != 3 && c + 1 < chunks) continue;
+        if (ST == 3 && (c & 1) != 1 && c + 1 < chunks) continue;
+        if (ST == 4) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(&g_cursor, (unsigned long long)((pending + 255) & ~255u));
+            at = __shfl(at, 0, 64);
+            o = dst + at;
+        }
         for (uint32_t i = lane * 16; i < pending; i += 1024) {
-            if (ST == 1) __builtin_nontemporal_store(acc, (u32x4*)(o + i)); else *(u32x4*)(o + i) = acc;
+            if (ST == 1 || ST >= 3) __builtin_nontemporal_store(acc, (u32x4*)(o + i)); else *(u32x4*)(o + i) = acc;
         }
         o += pending; pending = 0;
     }
@@ -160,6 +172,22 @@ int main()
             printf("wave_rw nt      wout=%4u : %.3f ms  read %.2f TB/s + write %.2f TB/s\n", wout, ms, bytes/ms/1e9, nseg*(double)chunks*wout/ms/1e9);
             ms = timeit([&]{ hipLaunchKernelGGL(k_wave_rw<2>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, wout, nseg, slot); });
             printf("wave_rw batch4  wout=%4u : %.3f ms  read %.2f TB/s + write %.2f TB/s\n", wout, ms, bytes/ms/1e9, nseg*(double)chunks*wout/ms/1e9);
+            ms = timeit([&]{ hipLaunchKernelGGL(k_wave_rw<3>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, wout, nseg, slot); });
+            printf("wave_rw nt x2   wout=%4u : %.3f ms  read %.2f TB/s + write %.2f TB/s\n", wout, ms, bytes/ms/1e9, nseg*(double)chunks*wout/ms/1e9);
+            ms = timeit([&]{ hipLaunchKernelGGL(k_reset_cursor, dim3(1), dim3(1), 0, 0); hipLaunchKernelGGL(k_wave_rw<4>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, wout, nseg, slot); });
+            printf("wave_rw nt log  wout=%4u : %.3f ms  read %.2f TB/s + write %.2f TB/s\n", wout, ms, bytes/ms/1e9, nseg*(double)chunks*wout/ms/1e9);
+        }
+    }
+    {   // the codec's real geometry: 2-chunk segments
+        const uint32_t chunks = 2; const size_t nseg = bytes / ((size_t)chunks * 16384);
+        for (uint32_t wout : {2816u, 3072u}) {
+            const size_t slot = (size_t)chunks * 4224;
+            float ms = timeit([&]{ hipLaunchKernelGGL(k_wave_rw<1>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, wout, nseg, slot); });
+            printf("seg2 wave_rw nt     wout=%4u : %.3f ms\n", wout, ms);
+            ms = timeit([&]{ hipLaunchKernelGGL(k_wave_rw<3>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, wout, nseg, slot); });
+            printf("seg2 wave_rw nt x2  wout=%4u : %.3f ms\n", wout, ms);
+            ms = timeit([&]{ hipLaunchKernelGGL(k_reset_cursor, dim3(1), dim3(1), 0, 0); hipLaunchKernelGGL(k_wave_rw<4>, dim3((nseg+3)/4), dim3(256), 0, 0, src, dst, chunks, wout, nseg, slot); });
+            printf("seg2 wave_rw nt log wout=%4u : %.3f ms\n", wout, ms);
         }
     }
     {
