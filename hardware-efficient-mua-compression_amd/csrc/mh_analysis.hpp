@@ -6,8 +6,9 @@
 //                   np.mean / np.max of a design point's per-channel bit rates
 // float64 sums follow NumPy's pairwise summation (numpy/core/src/umath/loops_utils.h.src,
 // pairwise_sum_DOUBLE: blocks of <= 128 with eight running sums, halves split at a multiple of 8),
-// with floating-point contraction switched OFF in every function (HIP's __dadd_rn / __dmul_rn are
-// plain operators: without the pragma hipcc fuses a*b+c into one FMA and the last bits differ).
+// written with plain operators under `#pragma clang fp contract(off)` in every function: without it
+// hipcc fuses a*b+c into one FMA and the last bits differ (HIP's __dadd_rn / __dmul_rn do not help --
+// they are inline operators that carry the header's own contraction setting).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,7 +28,7 @@ __device__ inline double pairwise_block(const VecRef &a, uint64_t lo, uint64_t n
 #pragma clang fp contract(off)
     if (n < 8) {
         double res = 0.;
-        for (uint64_t i = 0; i < n; ++i) res = __dadd_rn(res, a.at(lo + i));
+        for (uint64_t i = 0; i < n; ++i) res = res + a.at(lo + i);
         return res;
     }
     double r[8];
@@ -36,10 +37,9 @@ __device__ inline double pairwise_block(const VecRef &a, uint64_t lo, uint64_t n
     uint64_t i = 8;
     for (; i < n - (n % 8); i += 8)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], a.at(lo + i + j));
-    double res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
-                           __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
-    for (; i < n; ++i) res = __dadd_rn(res, a.at(lo + i));
+        for (int j = 0; j < 8; ++j) r[j] = r[j] + a.at(lo + i + j);
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a.at(lo + i);
     return res;
 }
 
@@ -71,7 +71,7 @@ __device__ inline double pairwise_sum(const VecRef &a, uint64_t n)
                     n = N - n2;
                     break;
                 }
-                ret = __dadd_rn(acc_st[sp - 1], ret);
+                ret = acc_st[sp - 1] + ret;
                 --sp;
             }
             continue;
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void k_power_draws(const double *br, const int
     if (d >= n_draws) return;
     VecRef a{br, idx + d, n_draws};
     const double s = pairwise_sum(a, Z);
-    const double temp = __dadd_rn(__dadd_rn(__dmul_rn(comm_energy, s), per_channels), static_power);
-    x[d * x_stride] = __dadd_rn(x[d * x_stride], temp);
+    const double temp = comm_energy * s + per_channels + static_power;  // left to right, as Python evaluates :104
+    x[d * x_stride] = x[d * x_stride] + temp;
 }
 
 // One thread per row r = vals[row_off[r] .. row_off[r+1]): pairwise sum and np.max (NaN propagates).

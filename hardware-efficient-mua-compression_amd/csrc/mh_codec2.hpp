@@ -314,9 +314,12 @@ __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t 
 // consumed the slot is refilled with the row 8 KiB further on (this chunk, then the next one).
 // ABL (debug ablation, 0 in production): 1 no global stores, 2 also no merge, 3 also no staging
 // writes, 4 loads only
-template <int LC, int PB, int ABL = 0>
+// HAS_NEXT is a template constant on purpose: with a run-time flag the refill loads of the second half
+// sit in a branch, the compiler's wait-count pass cannot count them, and every vmcnt in that half
+// tightens by one per row down to vmcnt(0) -- the wave then drains its whole window at each chunk end.
+template <int LC, int PB, int ABL, bool HAS_NEXT>
 __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_t *__restrict__ cur,
-                                                  bool has_next, const uint2 *lut2, const uint2 *lut1,
+                                                  const uint2 *lut2, const uint2 *lut1,
                                                   uint32_t *buf, uint32_t cap, uint32_t *__restrict__ &dst,
                                                   uint32_t &pend, int lane, uint32_t &words, uint32_t &bits)
 {
@@ -334,7 +337,7 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         u32x4 x = v[k & (kWin - 1)];
-        if (k < kRows - kWin || has_next)
+        if (k < kRows - kWin || HAS_NEXT)
             v[k & (kWin - 1)] = load_row(cur + ((uint32_t)(k + kWin) * kLanes + lane) * MH_PIECE);
         if (ABL == 4) {
             acc += x.x ^ x.y ^ x.z ^ x.w;
@@ -475,7 +478,10 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
 __device__ __forceinline__ void load_first_rows(u32x4 (&v)[kWin], const uint8_t *src, int lane)
 {
 #pragma unroll
-    for (int k = 0; k < kWin; ++k) v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
+    for (int k = 0; k < kWin; ++k) {
+        v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
+        asm volatile("" ::: "memory");  // keep the rows in issue order: vmcnt retires in order
+    }
 }
 
 // src = first sample, n = samples, out = the segment's slot.  PRE: the caller has already issued
@@ -492,13 +498,16 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
     uint64_t words = 0, bits = 0;
     if (nfull) {
         if (!PRE) load_first_rows(v, src, lane);
-        for (uint32_t c = 0; c < nfull; ++c) {
-            uint32_t w, b;
-            encode_full_chunk<LC, PB, ABL>(v, src + (size_t)c * kChunk, c + 1 < nfull, lut2, lut1, buf, cap,
-                                           out, pend, lane, w, b);
+        uint32_t w, b;
+        for (uint32_t c = 0; c + 1 < nfull; ++c) {
+            encode_full_chunk<LC, PB, ABL, true>(v, src + (size_t)c * kChunk, lut2, lut1, buf, cap, out, pend, lane, w, b);
             words += w;
             bits += b;
         }
+        encode_full_chunk<LC, PB, ABL, false>(v, src + (size_t)(nfull - 1) * kChunk, lut2, lut1, buf, cap, out, pend, lane,
+                                              w, b);
+        words += w;
+        bits += b;
     }
     if (rem) {
         const uint4 r = encode_partial_chunk<LC, PB>(src + (size_t)nfull * kChunk, rem, lut2, lut1, buf, cap, out, pend,

@@ -178,6 +178,17 @@ int main()
             printf("wave_rw nt log  wout=%4u : %.3f ms  read %.2f TB/s + write %.2f TB/s\n", wout, ms, bytes/ms/1e9, nseg*(double)chunks*wout/ms/1e9);
         }
     }
+    {   // occupancy sensitivity of the codec-shaped mix (2-chunk segments, nt stores): dynamic LDS limits
+        // the workgroups per CU (160 KiB / lds)
+        const uint32_t chunks = 2; const size_t nseg = bytes / ((size_t)chunks * 16384);
+        const size_t slot = (size_t)chunks * 4224;
+        for (int wg_per_cu : {2, 3, 4, 5, 6, 8}) {
+            const size_t lds = (size_t)160 * 1024 / wg_per_cu - 1024;
+            CK(hipFuncSetAttribute((const void*)k_wave_rw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            float ms = timeit([&]{ hipLaunchKernelGGL(k_wave_rw<1>, dim3((nseg+3)/4), dim3(256), lds, 0, src, dst, chunks, 2816u, nseg, slot); });
+            printf("seg2 wave_rw nt wout=2816, %d workgroups/CU : %.3f ms\n", wg_per_cu, ms);
+        }
+    }
     {   // the codec's real geometry: 2-chunk segments
         const uint32_t chunks = 2; const size_t nseg = bytes / ((size_t)chunks * 16384);
         for (uint32_t wout : {2816u, 3072u}) {
