@@ -902,7 +902,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
     const uint32_t rem = (uint32_t)(n % kChunk);
 #define MH_DEC_BAIL()                              \
     do {                                           \
-        if (lane == 0) atomicOr(d.err, 1u);        \
+        if (lane == 0) atomicMax(d.err, d.epoch);  \
         return;                                    \
     } while (0)
     if (nfull) {
