@@ -490,7 +490,8 @@ __device__ __forceinline__ void load_first_rows(u32x4 (&v)[kWin], const uint8_t 
 template <int LC, int PB, int ABL, bool PRE>
 __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, uint32_t ch, const uint8_t *src, uint64_t n,
                                                uint32_t *__restrict__ out, u32x4 (&v)[kWin], const uint2 *lut2,
-                                               const uint2 *lut1, uint32_t *buf, uint32_t cap, int lane)
+                                               const uint2 *lut1, uint32_t *buf, uint32_t cap, int lane,
+                                               uint64_t &seg_bits)
 {
     uint32_t pend = 0;  // words waiting in LDS behind `out` (the next unflushed word)
     const uint32_t nfull = (uint32_t)(n / kChunk);
@@ -520,8 +521,9 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
     if (ABL < 1 && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
     if (lane == 0) {
         e.seg_words[seg] = words;
-        atomicAdd(&e.ch_bits[ch], (unsigned long long)bits);
+        if (!PRE || e.cal_mode == 0) atomicAdd(&e.ch_bits[ch], (unsigned long long)bits);  // zeroed by k_calibrate
     }
+    seg_bits = bits;
 }
 
 // Long channels: a workgroup owns up to 4 consecutive segments OF ONE CHANNEL and shares its tables.
@@ -553,8 +555,9 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
     const uint32_t seg = seg0 + (uint32_t)wave;
     u32x4 v[kWin];
+    uint64_t bits;
     encode_segment<LC, PB, ABL, false>(a.e, seg, ch, a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg],
-                                       a.e.seg_n[seg], a.e.payload + a.e.seg_off[seg], v, lut2, lut1, buf, cap, lane);
+                                       a.e.seg_n[seg], a.e.payload + a.e.seg_off[seg], v, lut2, lut1, buf, cap, lane, bits);
 }
 
 // Short channels (the reference's real recordings at 50 ms bins are 2e4-7e4 samples per channel,
@@ -578,14 +581,37 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
     uint2 *lut1 = reinterpret_cast<uint2 *>(wbase + 512);
     const uint8_t *src = a.e.data + t.src_off;
     u32x4 v[kWin];
+    uint2 el = make_uint2(0u, 0u);  // the 16 single-symbol entries {bit-reversed code, length}, one per lane
+    if (a.e.cal_mode == 0) {
+        if (lane < kLut) el = a.e.lut[(size_t)t.ch * kLut + lane];
+        if (t.n >= (uint32_t)kChunk) load_first_rows(v, src, lane);  // in flight during the table build
+    } else {
+        if (t.n >= (uint32_t)kChunk) load_first_rows(v, src, lane);
+        const int S = (int)a.e.S;
+        int p;
+        uint32_t k;
+        if (a.e.cal_mode == 1) {
+            wave_calibrate(a.e.data + t.cal_off, t.cal_n, S, a.e.mode, a.e.K, a.e.sclv, lane, p, k);
+        } else {  // preset word; out-of-range values decode as 0 like k_lut_preset
+            p = a.e.peak_in[t.ch] < S ? a.e.peak_in[t.ch] : 0;
+            k = a.e.enc_in[t.ch] < a.e.K ? a.e.enc_in[t.ch] : 0;
+        }
+        if (lane < kLut) {
+            const int sym = lane > S - 1 ? S - 1 : lane;
+            const uint32_t e = a.e.codes[k * 16 + rank_of_symbol((int)a.e.mode, S, p, sym)];
+            el = make_uint2(e & 0xFFFFu, e >> 16);
+        }
+        if ((t.flags & 1u) && lane == 0) {  // the channel's first record publishes its word
+            if (a.e.peak_out) a.e.peak_out[t.ch] = (uint8_t)p;
+            if (a.e.enc_out) a.e.enc_out[t.ch] = (uint8_t)k;
+            if (a.e.skip_out) a.e.skip_out[t.ch] = (uint8_t)((t.flags >> 1) & 1u);
+        }
+    }
     {
-        const uint2 *g = a.e.lut + (size_t)t.ch * kLut;
-        const uint2 el = lane < kLut ? g[lane] : make_uint2(0u, 0u);  // the 16 single-symbol entries, one per lane
-        if (t.n >= (uint32_t)kChunk) load_first_rows(v, src, lane);   // in flight during the table build
         constexpr uint32_t m = (1u << PB) - 1u;
 #pragma unroll
         for (uint32_t t0 = 0; t0 < (1u << (2 * PB)); t0 += 64) {
-            const uint32_t t = t0 + (uint32_t)lane, b0 = t & m, b1 = (t >> PB) & m;
+            const uint32_t tt = t0 + (uint32_t)lane, b0 = tt & m, b1 = (tt >> PB) & m;
             const uint32_t ax = __shfl(el.x, (int)b0, 64), ay = __shfl(el.y, (int)b0, 64);
             const uint32_t bx = __shfl(el.x, (int)b1, 64), by = __shfl(el.y, (int)b1, 64);
             uint32_t idx = b0 | (b1 << PB);
@@ -595,8 +621,24 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
         if (lane < kLut) lut1[lane] = el;
     }
     MH_WAVE_SYNC();
-    encode_segment<LC, PB, 0, true>(a.e, t.seg, t.ch, src, t.n, a.e.payload + t.dst_off, v, lut2, lut1,
-                                    wbase + kEncSharedDw, cap, lane);
+    uint64_t bits = 0;
+    if (t.n)
+        encode_segment<LC, PB, 0, true>(a.e, t.seg, t.ch, src, t.n, a.e.payload + t.dst_off, v, lut2, lut1,
+                                        wbase + kEncSharedDw, cap, lane, bits);
+    if (a.e.cal_mode != 0 && lane == 0) {
+        // Bit total of the channel without a zeroing launch: every record adds into plan scratch and
+        // takes a ticket; both are returning device-scope atomics, the ticket is issued only after
+        // the add has returned (performed at the coherence point), so whoever draws the last ticket
+        // sees every add.  It stores the total and leaves the scratch zero for the next launch.
+        const unsigned long long before = atomicAdd(&a.e.acc[t.ch], (unsigned long long)bits);
+        uint32_t one = 1u;
+        asm volatile("" : "+v"(one) : "v"((uint32_t)before));  // the ticket depends on the returned value
+        const uint32_t ticket = atomicAdd(&a.e.cnt[t.ch], one);
+        if (ticket + 1 == t.nseg_ch) {
+            a.e.ch_bits[t.ch] = atomicExch(&a.e.acc[t.ch], 0ull);
+            atomicExch(&a.e.cnt[t.ch], 0u);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -289,7 +289,73 @@ struct EncArgs {
     unsigned long long *ch_bits;
     uint32_t nseg;
     uint32_t stage_dw;  // staging dwords per lane = 8 * maxlen (256 samples * maxlen / 32)
+    // per-wave-table kernel only: where the wave gets its channel's (peak, encoder) word from
+    //   0  the LUT that k_calibrate / k_lut_preset wrote (`lut`)
+    //   1  calibrates in the wave (window of <= kCalDirect samples) -- mh_encode is one launch
+    //   2  the caller's preset word (peak_in / enc_in) -- mh_encode_preset is one launch
+    uint32_t cal_mode;
+    uint32_t S, mode, K;
+    const uint8_t *sclv;          // K*S lengths
+    const uint32_t *codes;        // K*16 bit-reversed code | len << 16, by rank
+    const uint8_t *peak_in, *enc_in;
+    uint8_t *peak_out, *enc_out, *skip_out;  // published by the channel's first record; may be NULL
+    // cal_mode != 0: per-channel bit totals are collected in plan scratch (acc, cnt -- zero between
+    // launches) and the LAST record of a channel to finish stores the total to ch_bits and re-zeroes
+    unsigned long long *acc;
+    uint32_t *cnt;
 };
+
+// Calibration of one channel by one wave (the body of k_calibrate for windows of <= 4096 samples):
+// histogram of min(x, S-1) over x[0, c), first-max peak, approx-sort ranks, first-min encoder over
+// the K rows -- lane k prices encoder k, so K = 35 costs as much as K = 1.
+// Compressing data/get_BR_with_approx_sort.py:164-176, 254, 281; functions_1.py:75-90.
+__device__ __forceinline__ void wave_calibrate(const uint8_t *x, uint32_t c, int S, uint32_t mode, uint32_t K,
+                                               const uint8_t *sclv, int lane, int &p_out, uint32_t &k_out)
+{
+    uint32_t cnt[MH_LUT_SYMS];
+#pragma unroll
+    for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = 0;
+    for (uint32_t i = lane; i < c; i += 64) {
+        int v = x[i];
+        v = v > S - 1 ? S - 1 : v;
+#pragma unroll
+        for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] += (v == s);
+    }
+#pragma unroll
+    for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = s < S ? wave_sum_u32(cnt[s]) : 0u;
+    int p = 0;
+    if (mode == MH_MODE_APPROX) {
+        uint32_t best = cnt[0];
+#pragma unroll
+        for (int s = 1; s < MH_LUT_SYMS; ++s)
+            if (s < S && cnt[s] > best) {  // first max wins (np.argmax)
+                best = cnt[s];
+                p = s;
+            }
+    }
+    uint32_t sorted[MH_LUT_SYMS];
+#pragma unroll
+    for (int k = 0; k < MH_LUT_SYMS; ++k) {
+        const int sym = k < S ? symbol_of_rank((int)mode, S, p, k) : 0;
+        uint32_t v = 0;
+#pragma unroll
+        for (int s = 0; s < MH_LUT_SYMS; ++s) v = (s == sym) ? cnt[s] : v;
+        sorted[k] = k < S ? v : 0;
+    }
+    // cost <= 9 * 4096 < 2^24 and k < 256: (cost << 8 | k) orders by cost, then by encoder index
+    uint32_t key = 0xFFFFFFFFu;
+    for (uint32_t k = lane; k < K; k += 64) {
+        uint32_t cost = 0;
+#pragma unroll
+        for (int r = 0; r < MH_LUT_SYMS; ++r)
+            if (r < S) cost += (uint32_t)sclv[k * S + r] * sorted[r];
+        const uint32_t kk = (cost << 8) | k;
+        key = kk < key ? kk : key;
+    }
+    key = wave_min(key);
+    p_out = p;
+    k_out = key & 0xFFu;
+}
 
 // ------------------------------------------------------------------------------------------
 // decode

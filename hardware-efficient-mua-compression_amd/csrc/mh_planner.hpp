@@ -62,15 +62,20 @@ inline uint64_t slot_words(uint64_t n, uint32_t maxlen)
     return (words + 31) & ~(uint64_t)31;
 }
 
-// One wave task of the per-wave-table kernels: everything the wave needs to start, in one 32-byte
+// One wave task of the per-wave-table kernels: everything the wave needs to start, in one 48-byte
 // record (one scalar load instead of the task -> segment -> channel chain of dependent loads).
+// A channel without segments (window empty or skipped) still gets one record with n = 0, so that
+// the encoder -- which calibrates inside the wave -- reports its (peak, encoder) word too.
 struct WaveTask {
-    uint64_t src_off;  // bytes from the data pointer to the segment's first sample
-    uint64_t dst_off;  // the segment's slot, words from the payload pointer
-    uint32_t n;        // samples
-    uint32_t ch;       // channel
-    uint32_t seg;      // directory entry
-    uint32_t pad;
+    uint64_t src_off;   // bytes from the data pointer to the segment's first sample
+    uint64_t dst_off;   // the segment's slot, words from the payload pointer
+    uint64_t cal_off;   // bytes from the data pointer to the channel's first bin (calibration window)
+    uint32_t n;         // samples (0: calibrate-only record)
+    uint32_t ch;        // channel
+    uint32_t seg;       // directory entry (unused when n == 0)
+    uint32_t cal_n;     // calibration window min(2^h, T), when it is short enough to scan in the wave
+    uint32_t nseg_ch;   // records of this channel (the last wave to finish publishes the channel's bit total)
+    uint32_t flags;     // bit 0: first record of the channel (publishes peak / encoder / skipped); bit 1: skipped
 };
 
 struct PlanHost {
@@ -88,6 +93,7 @@ struct PlanHost {
     // wave tasks of the per-wave-table kernels: every segment once, longest first
     std::vector<WaveTask> wave_tasks;
     bool use_wave_tasks = false;
+    bool fused_calibration = false;  // wave tasks calibrate in the wave (2^h <= kCalDirect): encode is ONE launch
     // window-histogram tiles, calibration tiles (windows above kCalDirect samples)
     std::vector<uint32_t> tile_ch, tile_n, cal_tile_ch, cal_tile_n;
     std::vector<uint64_t> tile_start, cal_tile_start;
@@ -214,19 +220,43 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
     // (channels of a few segments); their wave tasks run longest first
     p.use_wave_tasks = padded_waves * 15 > (uint64_t)I.n_segments * 16;
     if (tune.wave_tasks >= 0) p.use_wave_tasks = tune.wave_tasks != 0;
+    const uint64_t lim = (uint64_t)1 << I.h;
+    p.fused_calibration = p.use_wave_tasks && lim <= kCalDirect;
     if (p.use_wave_tasks) {
         std::vector<uint32_t> order(p.seg_ch.size());
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return p.seg_n[a] > p.seg_n[b]; });
-        p.wave_tasks.resize(order.size());
-        for (size_t i = 0; i < order.size(); ++i) {
-            const uint32_t s = order[i], c = p.seg_ch[s];
-            p.wave_tasks[i] = WaveTask{ch_off[c] + p.w0[c] + p.seg_first[s], p.seg_off[s], (uint32_t)p.seg_n[s], c, s, 0u};
+        std::vector<uint32_t> nseg_ch(C, 0);
+        for (uint32_t c : p.seg_ch) ++nseg_ch[c];
+        p.wave_tasks.reserve(order.size() + C);
+        auto record = [&](uint32_t c) {
+            WaveTask t{};
+            t.cal_off = ch_off[c];
+            t.ch = c;
+            t.cal_n = (uint32_t)(ch_len[c] < lim ? ch_len[c] : (lim <= kCalDirect ? lim : 0));
+            t.nseg_ch = nseg_ch[c] ? nseg_ch[c] : 1;
+            t.flags = p.skip[c] ? 2u : 0u;
+            return t;
+        };
+        for (uint32_t s : order) {
+            const uint32_t c = p.seg_ch[s];
+            WaveTask t = record(c);
+            t.src_off = ch_off[c] + p.w0[c] + p.seg_first[s];
+            t.dst_off = p.seg_off[s];
+            t.n = (uint32_t)p.seg_n[s];
+            t.seg = s;
+            if (p.seg_first[s] == 0) t.flags |= 1u;
+            p.wave_tasks.push_back(t);
         }
+        for (uint32_t c = 0; c < C; ++c)  // calibrate-only records, after the real work
+            if (!nseg_ch[c]) {
+                WaveTask t = record(c);
+                t.flags |= 1u;
+                p.wave_tasks.push_back(t);
+            }
     }
     // calibration: one wave per channel reads the window directly up to kCalDirect samples (the
     // reference's range is 2^2..2^10); longer windows go through the tiled histogram kernel
-    const uint64_t lim = (uint64_t)1 << I.h;
     if (lim > kCalDirect)
         for (uint32_t c = 0; c < C; ++c) {
             const uint64_t n = ch_len[c] < lim ? ch_len[c] : lim;

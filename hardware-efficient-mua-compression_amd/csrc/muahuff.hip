@@ -94,6 +94,8 @@ struct mh_plan {
     uint64_t *d_cal_tile_start = nullptr;
     unsigned long long *d_calhist = nullptr;
     uint2 *d_dtab2 = nullptr;  // 4-symbol decode tables (dec_K == 4 plans only)
+    unsigned long long *d_acc = nullptr;  // wave-task encoder: per-channel bit totals in flight (zero between launches)
+    uint32_t *d_cnt = nullptr;            //   and finished-record tickets
     uint32_t *d_err = nullptr;  // decode status word (mh_decode_status): epoch of the last failed decode
     uint32_t epoch = 0;         // number of mh_decode calls on this plan
 };
@@ -344,7 +346,7 @@ int mh_plan_destroy(mh_plan *p)
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
                     p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_dtab2, p->d_scan,
-                    p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err};
+                    p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err, p->d_acc, p->d_cnt};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -372,6 +374,8 @@ static int plan_upload(mh_plan *p)
         (H.use_wave_tasks && (rc = upload(&p->d_wave_tasks, H.wave_tasks))) ||
         (H.dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << H.W))) ||
         (rc = alloc(&p->d_scan, H.seg_ch.size() / mh::kScanBlock + 2)) || (rc = upload(&p->d_err, std::vector<uint32_t>(1, 0u))) ||
+        (H.use_wave_tasks && ((rc = upload(&p->d_acc, std::vector<unsigned long long>(C, 0ull))) ||
+                              (rc = upload(&p->d_cnt, std::vector<uint32_t>(C, 0u))))) ||
         (cal && ((rc = upload(&p->d_cal_tile_ch, H.cal_tile_ch)) || (rc = upload(&p->d_cal_tile_n, H.cal_tile_n)) ||
                  (rc = upload(&p->d_cal_tile_start, H.cal_tile_start)) ||
                  (rc = alloc(&p->d_calhist, (size_t)C * mh::kHistStride)))))
@@ -533,11 +537,26 @@ static mh::TaskArgs task_args(const mh_plan *p)
     return t;
 }
 
+// cal_mode: see EncArgs.  Modes 1 and 2 exist for wave-task plans only.
 static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t *seg_words,
-                         uint64_t *ch_bits, hipStream_t st)
+                         uint64_t *ch_bits, uint32_t cal_mode, const uint8_t *peak_in, const uint8_t *enc_in,
+                         uint8_t *peak_out, uint8_t *enc_out, uint8_t *skip_out, hipStream_t st)
 {
-    if (p->h.info.n_segments == 0) return MH_OK;
+    if (cal_mode == 0 && p->h.info.n_segments == 0) return MH_OK;
     mh::EncArgs a;
+    a.cal_mode = cal_mode;
+    a.S = p->h.info.S;
+    a.mode = p->h.info.mode;
+    a.K = p->h.info.K;
+    a.sclv = p->d_sclv;
+    a.codes = p->d_codes;
+    a.peak_in = peak_in;
+    a.enc_in = enc_in;
+    a.peak_out = peak_out;
+    a.enc_out = enc_out;
+    a.skip_out = skip_out;
+    a.acc = p->d_acc;
+    a.cnt = p->d_cnt;
     a.data = data;
     a.ch_off = p->d_ch_off;
     a.w0 = p->d_w0;
@@ -569,11 +588,13 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
                     (unsigned long long)payload_cap_words,
                     (unsigned long long)p->h.info.payload_cap_words);
     hipStream_t st = (hipStream_t)stream;
+    if (p->h.fused_calibration)  // short channels: every wave calibrates its own channel, one launch in all
+        return encode_common(p, data, payload, seg_words, ch_bits, 1u, nullptr, nullptr, peak, enc, skipped, st);
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
     int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st, nullptr,
                               reinterpret_cast<unsigned long long *>(ch_bits), skipped);
     if (rc) return rc;
-    return encode_common(p, data, payload, seg_words, ch_bits, st);
+    return encode_common(p, data, payload, seg_words, ch_bits, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 int mh_encode_preset(mh_plan *p, const uint8_t *data, const uint8_t *peak, const uint8_t *enc,
@@ -588,11 +609,13 @@ int mh_encode_preset(mh_plan *p, const uint8_t *data, const uint8_t *peak, const
                     (unsigned long long)payload_cap_words,
                     (unsigned long long)p->h.info.payload_cap_words);
     hipStream_t st = (hipStream_t)stream;
+    if (p->h.use_wave_tasks)  // the waves build their tables from the preset word themselves: one launch
+        return encode_common(p, data, payload, seg_words, ch_bits, 2u, peak, enc, nullptr, nullptr, nullptr, st);
     hipLaunchKernelGGL(mh::k_lut_preset, dim3((p->h.info.C + 15) / 16), dim3(256), 0, st, peak, enc,
                        (const uint32_t *)p->d_codes, p->h.info.C, p->h.info.S, p->h.info.mode, p->h.info.K, p->d_lut,
                        reinterpret_cast<unsigned long long *>(ch_bits), (uint8_t *)nullptr, (uint8_t *)nullptr);
     MH_HIP(hipGetLastError());
-    return encode_common(p, data, payload, seg_words, ch_bits, st);
+    return encode_common(p, data, payload, seg_words, ch_bits, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const uint64_t *seg_off,

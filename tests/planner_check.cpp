@@ -70,18 +70,32 @@ int main()
             covered += p.task_n[t];
         }
         CHECK(covered == n);
-        if (p.use_wave_tasks) {  // a permutation of the segments, longest first, records consistent with the directory
-            CHECK(p.wave_tasks.size() == n);
+        if (p.use_wave_tasks) {  // every segment once, longest first, then one record per channel without segments
             std::vector<uint8_t> seen(n, 0);
-            for (size_t i = 0; i < n; ++i) {
+            std::vector<uint32_t> per_ch(C, 0), first_ch(C, 0);
+            size_t nreal = 0;
+            for (size_t i = 0; i < p.wave_tasks.size(); ++i) {
                 const mh::WaveTask &t = p.wave_tasks[i];
+                CHECK(t.ch < C && t.cal_off == off[t.ch]);
+                CHECK(t.cal_n == (len[t.ch] < ((uint64_t)1 << h) ? len[t.ch] : (((uint64_t)1 << h) <= mh::kCalDirect ? ((uint64_t)1 << h) : 0)));
+                CHECK(((t.flags >> 1) & 1u) == p.skip[t.ch]);
+                ++per_ch[t.ch];
+                first_ch[t.ch] += t.flags & 1u;
+                if (t.n == 0) continue;
+                CHECK(nreal == i);  // real work first
+                ++nreal;
                 CHECK(t.seg < n && !seen[t.seg]);
                 seen[t.seg] = 1;
                 CHECK(t.ch == p.seg_ch[t.seg] && t.n == p.seg_n[t.seg] && t.dst_off == p.seg_off[t.seg]);
                 CHECK(t.src_off == off[t.ch] + p.w0[t.ch] + p.seg_first[t.seg]);
                 CHECK(t.src_off + t.n <= off[t.ch] + len[t.ch]);
+                CHECK((t.flags & 1u) == (p.seg_first[t.seg] == 0 ? 1u : 0u));
                 if (i) CHECK(p.wave_tasks[i - 1].n >= t.n);
             }
+            CHECK(nreal == n);
+            for (unsigned c = 0; c < C; ++c) CHECK(per_ch[c] >= 1 && first_ch[c] == 1);
+            for (const mh::WaveTask &t : p.wave_tasks) CHECK(t.nseg_ch == per_ch[t.ch]);
+            CHECK(p.fused_calibration == (((uint64_t)1 << h) <= mh::kCalDirect));
         }
         // histogram tiles cover the windows; calibration tiles cover min(2^h, T) when it is long
         uint64_t tiled = 0;
