@@ -626,17 +626,15 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
         encode_segment<LC, PB, 0, true>(a.e, t.seg, t.ch, src, t.n, a.e.payload + t.dst_off, v, lut2, lut1,
                                         wbase + kEncSharedDw, cap, lane, bits);
     if (a.e.cal_mode != 0 && lane == 0) {
-        // Bit total of the channel without a zeroing launch: every record adds into plan scratch and
-        // takes a ticket; both are returning device-scope atomics, the ticket is issued only after
-        // the add has returned (performed at the coherence point), so whoever draws the last ticket
-        // sees every add.  It stores the total and leaves the scratch zero for the next launch.
-        const unsigned long long before = atomicAdd(&a.e.acc[t.ch], (unsigned long long)bits);
-        uint32_t one = 1u;
-        asm volatile("" : "+v"(one) : "v"((uint32_t)before));  // the ticket depends on the returned value
-        const uint32_t ticket = atomicAdd(&a.e.cnt[t.ch], one);
-        if (ticket + 1 == t.nseg_ch) {
-            a.e.ch_bits[t.ch] = atomicExch(&a.e.acc[t.ch], 0ull);
-            atomicExch(&a.e.cnt[t.ch], 0u);
+        // Bit total of the channel without a zeroing launch: every record adds {bits << 24 | 1} to the
+        // channel's word in plan scratch with ONE returning device-scope atomic.  The record that sees
+        // nseg_ch - 1 earlier tickets in the returned value is the last one: the returned total plus its
+        // own bits is the channel's total; it stores it and leaves the scratch zero for the next launch.
+        // (The planner only enables this when ticket count and bit total fit their 24 / 40 bits.)
+        const unsigned long long before = atomicAdd(&a.e.acc[t.ch], ((unsigned long long)bits << 24) | 1ull);
+        if ((uint32_t)(before & 0xFFFFFFull) + 1u == t.nseg_ch) {
+            a.e.ch_bits[t.ch] = (before >> 24) + bits;
+            atomicExch(&a.e.acc[t.ch], 0ull);
         }
     }
 }

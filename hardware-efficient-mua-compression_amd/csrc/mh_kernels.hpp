@@ -299,10 +299,9 @@ struct EncArgs {
     const uint32_t *codes;        // K*16 bit-reversed code | len << 16, by rank
     const uint8_t *peak_in, *enc_in;
     uint8_t *peak_out, *enc_out, *skip_out;  // published by the channel's first record; may be NULL
-    // cal_mode != 0: per-channel bit totals are collected in plan scratch (acc, cnt -- zero between
-    // launches) and the LAST record of a channel to finish stores the total to ch_bits and re-zeroes
+    // cal_mode != 0: per-channel {bit total << 24 | finished records} words in plan scratch (zero
+    // between launches); the LAST record of a channel to finish stores the total to ch_bits and re-zeroes
     unsigned long long *acc;
-    uint32_t *cnt;
 };
 
 // Calibration of one channel by one wave (the body of k_calibrate for windows of <= 4096 samples):

@@ -94,6 +94,7 @@ struct PlanHost {
     std::vector<WaveTask> wave_tasks;
     bool use_wave_tasks = false;
     bool fused_calibration = false;  // wave tasks calibrate in the wave (2^h <= kCalDirect): encode is ONE launch
+    bool tickets_fit = false;        // every channel: records < 2^24 and 9 bits/sample * T < 2^40 (the packed total word)
     // window-histogram tiles, calibration tiles (windows above kCalDirect samples)
     std::vector<uint32_t> tile_ch, tile_n, cal_tile_ch, cal_tile_n;
     std::vector<uint64_t> tile_start, cal_tile_start;
@@ -228,6 +229,9 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return p.seg_n[a] > p.seg_n[b]; });
         std::vector<uint32_t> nseg_ch(C, 0);
         for (uint32_t c : p.seg_ch) ++nseg_ch[c];
+        p.tickets_fit = true;
+        for (uint32_t c = 0; c < C; ++c)
+            if (nseg_ch[c] >= (1u << 24) || ch_len[c] >= ((uint64_t)1 << 36)) p.tickets_fit = false;
         p.wave_tasks.reserve(order.size() + C);
         auto record = [&](uint32_t c) {
             WaveTask t{};

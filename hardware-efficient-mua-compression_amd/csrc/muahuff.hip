@@ -94,8 +94,7 @@ struct mh_plan {
     uint64_t *d_cal_tile_start = nullptr;
     unsigned long long *d_calhist = nullptr;
     uint2 *d_dtab2 = nullptr;  // 4-symbol decode tables (dec_K == 4 plans only)
-    unsigned long long *d_acc = nullptr;  // wave-task encoder: per-channel bit totals in flight (zero between launches)
-    uint32_t *d_cnt = nullptr;            //   and finished-record tickets
+    unsigned long long *d_acc = nullptr;  // wave-task encoder: per-channel {bits << 24 | finished records} (zero between launches)
     uint32_t *d_err = nullptr;  // decode status word (mh_decode_status): epoch of the last failed decode
     uint32_t epoch = 0;         // number of mh_decode calls on this plan
 };
@@ -346,7 +345,7 @@ int mh_plan_destroy(mh_plan *p)
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
                     p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_dtab2, p->d_scan,
-                    p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err, p->d_acc, p->d_cnt};
+                    p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err, p->d_acc};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -374,8 +373,7 @@ static int plan_upload(mh_plan *p)
         (H.use_wave_tasks && (rc = upload(&p->d_wave_tasks, H.wave_tasks))) ||
         (H.dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << H.W))) ||
         (rc = alloc(&p->d_scan, H.seg_ch.size() / mh::kScanBlock + 2)) || (rc = upload(&p->d_err, std::vector<uint32_t>(1, 0u))) ||
-        (H.use_wave_tasks && ((rc = upload(&p->d_acc, std::vector<unsigned long long>(C, 0ull))) ||
-                              (rc = upload(&p->d_cnt, std::vector<uint32_t>(C, 0u))))) ||
+        (H.use_wave_tasks && (rc = upload(&p->d_acc, std::vector<unsigned long long>(C, 0ull)))) ||
         (cal && ((rc = upload(&p->d_cal_tile_ch, H.cal_tile_ch)) || (rc = upload(&p->d_cal_tile_n, H.cal_tile_n)) ||
                  (rc = upload(&p->d_cal_tile_start, H.cal_tile_start)) ||
                  (rc = alloc(&p->d_calhist, (size_t)C * mh::kHistStride)))))
@@ -556,7 +554,6 @@ static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uin
     a.enc_out = enc_out;
     a.skip_out = skip_out;
     a.acc = p->d_acc;
-    a.cnt = p->d_cnt;
     a.data = data;
     a.ch_off = p->d_ch_off;
     a.w0 = p->d_w0;
@@ -588,7 +585,7 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
                     (unsigned long long)payload_cap_words,
                     (unsigned long long)p->h.info.payload_cap_words);
     hipStream_t st = (hipStream_t)stream;
-    if (p->h.fused_calibration)  // short channels: every wave calibrates its own channel, one launch in all
+    if (p->h.fused_calibration && p->h.tickets_fit)  // short channels: every wave calibrates its own channel, one launch in all
         return encode_common(p, data, payload, seg_words, ch_bits, 1u, nullptr, nullptr, peak, enc, skipped, st);
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
     int rc = launch_calibrate(p, data, nullptr, nullptr, pk, en, st, nullptr,
@@ -609,7 +606,7 @@ int mh_encode_preset(mh_plan *p, const uint8_t *data, const uint8_t *peak, const
                     (unsigned long long)payload_cap_words,
                     (unsigned long long)p->h.info.payload_cap_words);
     hipStream_t st = (hipStream_t)stream;
-    if (p->h.use_wave_tasks)  // the waves build their tables from the preset word themselves: one launch
+    if (p->h.use_wave_tasks && p->h.tickets_fit)  // the waves build their tables from the preset word themselves: one launch
         return encode_common(p, data, payload, seg_words, ch_bits, 2u, peak, enc, nullptr, nullptr, nullptr, st);
     hipLaunchKernelGGL(mh::k_lut_preset, dim3((p->h.info.C + 15) / 16), dim3(256), 0, st, peak, enc,
                        (const uint32_t *)p->d_codes, p->h.info.C, p->h.info.S, p->h.info.mode, p->h.info.K, p->d_lut,

@@ -4,7 +4,12 @@ import csv
 import sys
 from collections import defaultdict
 
+import os
+
 for path in sys.argv[1:]:
+    if not os.path.exists(path):
+        print("(missing: %s)" % path)
+        continue
     acc = defaultdict(lambda: defaultdict(list))
     with open(path) as f:
         for r in csv.DictReader(f):
