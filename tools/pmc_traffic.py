@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 
 usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
 HBM bytes per launch = FETCH_SIZE KiB * 1024 * 2 (gfx950 correction, /opt/skills/guides/MI355X_MICROARCH.md)
@@ -27,7 +27,7 @@ fetch, nf = mean_per_kernel(sys.argv[1], "FETCH_SIZE")
 write, nw = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate runs, tools/collect_pmc_traffic.sh) of "
-              "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gather`; mean over the launches",
+              "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gather --no-per-S --no-small-shape`; mean over the launches",
     "workload": {"channels_per_gpu": 1024, "bins": 10000000, "S": 3, "hist_bits": 6, "seg_chunks": 2},
     "correction": "bytes = FETCH_SIZE*1024*2 (gfx950 wide-read correction) + WRITE_SIZE*1024",
     "kernels": {},
