@@ -715,6 +715,9 @@ __host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W, uint32_t K)
     return ((K == 4 ? 2u : 1u) << W) + kDtab / 4;
 }
 
+// staging dwords per wave: whole 16-byte-per-lane vectors (1 KiB each) covering NR * 64 words
+__host__ __device__ inline uint32_t dec2_stage_dwords(uint32_t NR) { return ((NR + 3) / 4) * 256; }
+
 // Per-chunk pipeline state: the scanned header of the chunk about to be decoded.
 struct ChunkHdr {
     uint32_t P;   // this lane's sub-stream starts at bit P of the chunk payload
@@ -925,17 +928,33 @@ __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict_
 
 // One segment, one wave: the chunks of segment `seg` through the wave's tables (`tab` multi-symbol
 // table at LDS byte address `tbase`, `tab1` per-symbol table) and its payload staging area.
+//
+// Pipeline of the full chunks.  While chunk c decodes out of LDS, the payload of chunk c+1 (NV
+// 16-byte vectors per lane) and the first 32 words of chunk c+2 (its header) are on their way into
+// registers; they are moved to LDS at the END of the iteration, behind chunk c's 16 output stores.
+// Two rules keep the wave from draining those stores at every chunk (gfx9 retires loads and stores
+// through ONE in-order counter, and the compiler's wait-count pass only counts operations that are
+// certain to have been issued on every path to the wait):
+//   * every global load of the loop is unconditional, its index clamped -- never branched around;
+//   * the loads are consumed in the same straight-line stretch that issued the stores, so the
+//     wait in front of the register -> LDS copy is vmcnt(16 + k), not vmcnt(0).  (Consuming them at
+//     the top of the next iteration joins the loop entry -- no stores yet -- with the back edge, and
+//     the join has to assume the worst: vmcnt(0).)
+// The oversize-chunk slow path has loads of its own and therefore sits OUTSIDE the loop: the
+// first chunk that does not fit the staging area ends it and the rest of the segment goes chunk
+// by chunk through decode_chunk (adversarial data only).
 template <int K, int M, int NR, int RL, bool HY>
 __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, uint8_t *__restrict__ out, uint64_t n,
                                                const uint32_t *tab, uint32_t tbase, uint32_t maskW, const uint8_t *tab1,
                                                uint32_t mask1, uint32_t *stage, int lane)
 {
-    constexpr uint32_t kCap = NR * 64;
-    // Untrusted input: `pos` = word index of the chunk being entered, `lim` = words that may be
+    constexpr uint32_t kCap = NR * 64;         // words of payload (+3 read-ahead) a staged chunk may have
+    constexpr int NV = (NR + 3) / 4;           // 16-byte vectors per lane that cover kCap words
+    // Untrusted input: `pos` = word index of a chunk's first header word, `lim` = words that may be
     // read.  Before any read that a header value steers, the wave checks (wave-uniform, a few
     // scalar operations per chunk) that header + payload + 3 words of read-ahead (+ the next
     // chunk's first 32 words where there is one) lie below lim; otherwise the segment is abandoned
-    // and *err set.  Stores only ever go to the plan's own window positions.
+    // and *err raised.  Stores only ever go to the plan's own window positions.
     const uint64_t lim = d.payload_words;
     const uint32_t *in = d.payload + pos;
     const uint32_t nfull = (uint32_t)(n / kChunk);
@@ -945,54 +964,92 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
         if (lane == 0) atomicMax(d.err, d.epoch);  \
         return;                                    \
     } while (0)
+    uint32_t c = 0;  // next chunk the per-symbol loop below would have to decode
     if (nfull) {
-        uint32_t R[NR];
         if (pos + 32 > lim) MH_DEC_BAIL();
-        ChunkHdr cur = scan_header(in[lane & 31], lane);
-        if (pos + cur.hw + cur.nw + 3 + (nfull > 1 ? 32 : 0) > lim) MH_DEC_BAIL();
-        const uint32_t *pay = in + cur.hw;
-        uint32_t ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;  // 0: oversize chunk, slow path
+        ChunkHdr hc = scan_header(in[lane & 31], lane);  // chunk whose payload is (about to be) in LDS
+        if (pos + hc.hw + hc.nw + 3 + (nfull > 1 ? 32 : 0) > lim) MH_DEC_BAIL();
+        // words readable from a payload pointer on, capped so that 32-bit lane indices suffice (>= 4: nw + 3 fits)
+        auto room = [&](uint64_t at) { const uint64_t r = lim - at; return (uint32_t)(r < 0x40000000ull ? r : 0x40000000ull); };
+        u32x4 R[NV];
+        auto fetch = [&](const uint32_t *p, uint32_t av) {  // NV x 1 KiB, lane indices clamped below av
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-            if ((uint32_t)(j * 64) < ns) {  // wave-uniform; the index clamp keeps the last row inside nw + 2
-                const uint32_t i_ = (uint32_t)(j * 64 + lane);
-                R[j] = pay[i_ < ns ? i_ : ns - 1];
+            for (int j = 0; j < NV; ++j) {
+                uint32_t i_ = (uint32_t)(j * 256 + lane * 4);
+                i_ = i_ + 4 <= av ? i_ : av - 4;
+                R[j] = *reinterpret_cast<const u32x4_u *>(p + i_);
             }
-        uint32_t hw_next = 0;
-        if (nfull > 1) hw_next = pay[cur.nw + (lane & 31)];
-        for (uint32_t c = 0; c < nfull; ++c) {
+        };
+        auto peek = [&](const uint32_t *p, uint32_t at, uint32_t av) {  // word (lane & 31) behind a chunk, clamped
+            const uint32_t i_ = at + (uint32_t)(lane & 31);
+            return p[i_ < av ? i_ : av - 1];
+        };
+        auto to_lds = [&]() {
 #pragma unroll
-            for (int j = 0; j < NR; ++j)  // payload(c): registers -> LDS
-                if ((uint32_t)(j * 64) < ns) stage[j * 64 + lane] = R[j];
-            const ChunkHdr hc = cur;
-            const uint32_t *chunk_c = pay - cur.hw;  // first header word of chunk c
-            const bool staged = ns != 0;
+            for (int j = 0; j < NV; ++j) *reinterpret_cast<u32x4 *>(stage + j * 256 + lane * 4) = R[j];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (c + 1 < nfull) {  // fetch payload(c+1) and header(c+2) before this chunk's stores
-                const uint32_t *nextc = pay + cur.nw;  // chunk c+1
-                pos += cur.hw + cur.nw;
-                cur = scan_header(hw_next, lane);
-                if (pos + cur.hw + cur.nw + 3 + (c + 2 < nfull ? 32 : 0) > lim) MH_DEC_BAIL();
-                pay = nextc + cur.hw;
-                ns = cur.nw + 3 <= kCap ? cur.nw + 3 : 0;
-#pragma unroll
-                for (int j = 0; j < NR; ++j)
-                    if ((uint32_t)(j * 64) < ns) {
-                        const uint32_t i_ = (uint32_t)(j * 64 + lane);
-                        R[j] = pay[i_ < ns ? i_ : ns - 1];
-                    }
-                if (c + 2 < nfull) hw_next = pay[cur.nw + (lane & 31)];
+        };
+        if (hc.nw + 3 <= kCap) {
+            // ---- prologue: payload(0) -> LDS, header(1) scanned
+            const uint32_t *pay_n = in + hc.hw;  // payload of the chunk `nx` describes (chunk 0 as a stand-in while nfull == 1)
+            uint64_t pos_n = pos;                // that chunk's first header word
+            uint32_t avail_n = room(pos + hc.hw);
+            ChunkHdr nx = hc;
+            fetch(pay_n, avail_n);
+            uint32_t hw_next = peek(pay_n, hc.nw, avail_n);
+            to_lds();
+            // every load is consumed where it is certain to have landed, even when its value is not
+            // needed: a load left pending makes the compiler guard the reuse of its register with a
+            // full drain later on
+            asm volatile("" ::"v"(hw_next));
+            if (nfull > 1) {
+                pos_n += hc.hw + hc.nw;
+                nx = scan_header(hw_next, lane);
+                if (pos_n + nx.hw + nx.nw + 3 + (nfull > 2 ? 32 : 0) > lim) MH_DEC_BAIL();
+                pay_n += hc.nw + nx.hw;
+                avail_n = room(pos_n + nx.hw);
             }
-            if (staged)
+            for (;;) {
+                // payload(c+1) and the head of chunk c+2 (behind the last chunk: a harmless re-read), in
+                // flight before this chunk's stores
+                fetch(pay_n, avail_n);
+                hw_next = peek(pay_n, nx.nw, avail_n);
                 decode_staged_chunk<K, M, RL, HY>(hc, tab, tbase, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
-            else
-                decode_chunk<3, true>(chunk_c, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                ++c;
+                if (c == nfull) {  // `nx` / `pay_n` describe the last chunk (== hc)
+                    in = pay_n + nx.nw;
+                    pos = pos_n + nx.hw + nx.nw;
+                    break;
+                }
+                if (nx.nw + 3 > kCap) {  // oversize chunk next: the per-symbol loop takes over
+                    in = pay_n - nx.hw;
+                    pos = pos_n;
+                    break;
+                }
+                to_lds();  // payload(c) has landed behind the 16 stores: registers -> LDS
+                asm volatile("" ::"v"(hw_next));
+                hc = nx;
+                if (c + 1 < nfull) {  // scalar bookkeeping: header(c+1) from hw_next
+                    pos_n += nx.hw + nx.nw;
+                    pay_n += nx.nw;
+                    nx = scan_header(hw_next, lane);
+                    if (pos_n + nx.hw + nx.nw + 3 + (c + 2 < nfull ? 32 : 0) > lim) MH_DEC_BAIL();
+                    pay_n += nx.hw;
+                    avail_n = room(pos_n + nx.hw);
+                }
+            }
         }
-        in = pay + cur.nw;  // first word after the last full chunk
-        pos += cur.hw + cur.nw;
+    }
+    for (; c < nfull; ++c) {  // (rest of) a segment that holds an oversize chunk: per-symbol routine
+        if (pos + 32 > lim) MH_DEC_BAIL();
+        const ChunkHdr h = scan_header(in[lane & 31], lane);
+        if (pos + h.hw + h.nw + 3 > lim) MH_DEC_BAIL();
+        decode_chunk<3, true>(in, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
+        in += h.hw + h.nw;
+        pos += h.hw + h.nw;
     }
     if (rem)
         decode_partial_chunk<K, M, RL, HY>(in, rem, tab, tbase, maskW, tab1, mask1, stage, kCap, out + (size_t)nfull * kChunk,
@@ -1047,7 +1104,7 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
     }
     __syncthreads();
     if ((uint32_t)wave >= nseg) return;
-    uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * (NR * 64);
+    uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * dec2_stage_dwords(NR);
     const uint32_t seg = seg0 + (uint32_t)wave;
     decode_segment<K, M, NR, RL, HY>(a.d, a.d.seg_off[seg], a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg],
                                      a.d.seg_n[seg], tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
@@ -1067,7 +1124,7 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
     const uint32_t W = a.W;
     const int S = (int)a.S;
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;
-    const uint32_t wdw = dec2_shared_dwords(W, K) + NR * 64;  // dwords per wave
+    const uint32_t wdw = dec2_shared_dwords(W, K) + dec2_stage_dwords(NR);  // dwords per wave
     uint32_t *tab = smem + (size_t)wave * wdw;
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (kEntDw << W));
     const uint64_t pos = a.plan_slots ? t.dst_off : a.d.seg_off[t.seg];

@@ -220,12 +220,12 @@ template <int K, int M, int NR, int RL, bool HY>
 static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st)
 {
     if (wave_tasks) {
-        const size_t lds = 4 * ((size_t)mh::dec2_shared_dwords(a.W, K) + (size_t)NR * 64) * sizeof(uint32_t);
+        const size_t lds = 4 * ((size_t)mh::dec2_shared_dwords(a.W, K) + mh::dec2_stage_dwords(NR)) * sizeof(uint32_t);
         auto kern = mh::k_decode2w<K, M, NR, RL, HY>;
         if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
         hipLaunchKernelGGL(kern, dim3((a.t.ntask + 3) / 4), dim3(256), lds, st, a);
     } else {
-        const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)NR * 64) * sizeof(uint32_t);
+        const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)mh::dec2_stage_dwords(NR)) * sizeof(uint32_t);
         auto kern = mh::k_decode2<K, M, NR, RL, HY>;
         if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, K == 2);
         hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
