@@ -969,10 +969,10 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
         if (pos + 32 > lim) MH_DEC_BAIL();
         ChunkHdr hc = scan_header(in[lane & 31], lane);  // chunk whose payload is (about to be) in LDS
         if (pos + hc.hw + hc.nw + 3 + (nfull > 1 ? 32 : 0) > lim) MH_DEC_BAIL();
-        // words readable from a payload pointer on, capped so that 32-bit lane indices suffice (>= 4: nw + 3 fits)
-        auto room = [&](uint64_t at) { const uint64_t r = lim - at; return (uint32_t)(r < 0x40000000ull ? r : 0x40000000ull); };
         u32x4 R[NV];
-        auto fetch = [&](const uint32_t *p, uint32_t av) {  // NV x 1 KiB, lane indices clamped below av
+        // NV x 1 KiB; lanes past the chunk's own av = nw + 3 words all re-read its last vector (one
+        // address: no extra traffic), so the instruction count is fixed but the bytes are the chunk's
+        auto fetch = [&](const uint32_t *p, uint32_t av) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 uint32_t i_ = (uint32_t)(j * 256 + lane * 4);
@@ -994,10 +994,12 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
             // ---- prologue: payload(0) -> LDS, header(1) scanned
             const uint32_t *pay_n = in + hc.hw;  // payload of the chunk `nx` describes (chunk 0 as a stand-in while nfull == 1)
             uint64_t pos_n = pos;                // that chunk's first header word
-            uint32_t avail_n = room(pos + hc.hw);
+            // words the next fetch / peek may touch: the chunk's nw + 3 (+ 32 of the following header);
+            // 4 once nothing follows (all lanes then re-read one vector)
+            uint32_t avail_n = hc.nw + 3, peek_n = hc.nw + (nfull > 1 ? 32 : 0);
             ChunkHdr nx = hc;
             fetch(pay_n, avail_n);
-            uint32_t hw_next = peek(pay_n, hc.nw, avail_n);
+            uint32_t hw_next = peek(pay_n, hc.nw, peek_n ? peek_n : 1);
             to_lds();
             // every load is consumed where it is certain to have landed, even when its value is not
             // needed: a load left pending makes the compiler guard the reuse of its register with a
@@ -1008,13 +1010,17 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
                 nx = scan_header(hw_next, lane);
                 if (pos_n + nx.hw + nx.nw + 3 + (nfull > 2 ? 32 : 0) > lim) MH_DEC_BAIL();
                 pay_n += hc.nw + nx.hw;
-                avail_n = room(pos_n + nx.hw);
+                avail_n = nx.nw + 3;
+                peek_n = nx.nw + (nfull > 2 ? 32 : 0);
+            } else {
+                avail_n = 4;
+                peek_n = 1;
             }
             for (;;) {
                 // payload(c+1) and the head of chunk c+2 (behind the last chunk: a harmless re-read), in
                 // flight before this chunk's stores
                 fetch(pay_n, avail_n);
-                hw_next = peek(pay_n, nx.nw, avail_n);
+                hw_next = peek(pay_n, nx.nw, peek_n);
                 decode_staged_chunk<K, M, RL, HY>(hc, tab, tbase, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1038,7 +1044,11 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
                     nx = scan_header(hw_next, lane);
                     if (pos_n + nx.hw + nx.nw + 3 + (c + 2 < nfull ? 32 : 0) > lim) MH_DEC_BAIL();
                     pay_n += nx.hw;
-                    avail_n = room(pos_n + nx.hw);
+                    avail_n = nx.nw + 3;
+                    peek_n = nx.nw + (c + 2 < nfull ? 32 : 0);
+                } else {
+                    avail_n = 4;  // nothing follows the chunk now in LDS: the next fetch is a one-vector re-read
+                    peek_n = 1;
                 }
             }
         }
