@@ -15,6 +15,7 @@
 // Partial (last) chunks of a channel go through the first-generation per-symbol routines.
 #pragma once
 #include "mh_kernels.hpp"
+#include "mh_layout.hpp"
 #include "mh_planner.hpp"
 
 namespace mh {
@@ -46,6 +47,32 @@ __host__ __device__ inline uint32_t enc2_wave_dwords(uint32_t stage_dw)
 // wave prefix sum, zero the chunk image in place, then OR every codeword into it with global
 // atomics.  Correct for any data; only adversarial inputs ever get here.
 // Returns {words written, code bits}.
+// Input packing PK of the encoder (template parameter throughout): 0 = one byte per sample (the
+// channel-major container), 4 / 2 = packed pieces written by k_deinterleave2<PK> for the time-major path.
+template <int PK>
+struct RawPiece { typedef u32x4 type; };
+template <>
+struct RawPiece<4> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <>
+struct RawPiece<2> { typedef uint32_t type; };
+template <int PK>
+constexpr uint32_t piece_bytes() { return PK == 0 ? 16u : PK == 4 ? 8u : 4u; }
+
+// sample `idx` (counted from `src`, which points at a piece boundary) of a byte / packed stream
+template <int PK>
+__device__ __forceinline__ uint32_t sample_at(const uint8_t *src, uint32_t idx)
+{
+    if (PK == 0) return src[idx];
+    const uint32_t piece = idx >> 4, i = idx & 15u, j = i & 3u, g = i >> 2;
+    if (PK == 4) {
+        const uint32_t d = reinterpret_cast<const uint32_t *>(src)[piece * 2 + (g >> 1)];
+        return (d >> (8 * j + 4 * (g & 1u))) & 15u;
+    }
+    const uint32_t d = reinterpret_cast<const uint32_t *>(src)[piece];
+    return (d >> (8 * j + 2 * g)) & 3u;
+}
+
+template <int PK>
 __device__ __forceinline__ uint2 encode_chunk_slow_body(const uint8_t *__restrict__ src, uint32_t m,
                                                         const uint2 *lut1, uint32_t *__restrict__ gdst,
                                                         int lane)
@@ -57,7 +84,7 @@ __device__ __forceinline__ uint2 encode_chunk_slow_body(const uint8_t *__restric
 #pragma unroll 1
         for (int i = 0; i < MH_PIECE; ++i)
             if (base + i < m) {
-                const uint32_t b = src[base + i];
+                const uint32_t b = sample_at<PK>(src, base + i);
                 tot += lut1[b > 15u ? 15u : b].y;
             }
     }
@@ -83,7 +110,7 @@ __device__ __forceinline__ uint2 encode_chunk_slow_body(const uint8_t *__restric
 #pragma unroll 1
         for (int i = 0; i < MH_PIECE; ++i)
             if (base + i < m) {
-                const uint32_t b = src[base + i];
+                const uint32_t b = sample_at<PK>(src, base + i);
                 const uint2 e = lut1[b > 15u ? 15u : b];
                 const uint64_t v = (uint64_t)e.x << (pos & 31);
                 atomicOr(&gpay[pos >> 5], (uint32_t)v);
@@ -98,11 +125,12 @@ __device__ __forceinline__ uint2 encode_chunk_slow_body(const uint8_t *__restric
 // Out of line for the full-chunk loop (keeps the hot kernel small).  The partial-chunk routine, itself
 // out of line, inlines the body instead: a call inside a callee would need a stack frame, and with
 // it scratch memory for every wave of the kernel.
+template <int PK>
 __device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src, uint32_t m,
                                                 const uint2 *lut1, uint32_t *__restrict__ gdst,
                                                 int lane)
 {
-    return encode_chunk_slow_body(src, m, lut1, gdst, lane);
+    return encode_chunk_slow_body<PK>(src, m, lut1, gdst, lane);
 }
 
 // LC: accumulator checks.  0 maxlen<=2: one per piece; 1 maxlen<=4: one per 2 dwords (8 codewords
@@ -136,9 +164,32 @@ __device__ __forceinline__ uint32_t clip_word(uint32_t d)
     return r;
 }
 
-__device__ __forceinline__ u32x4 load_row(const uint8_t *p)
+template <int PK>
+__device__ __forceinline__ typename RawPiece<PK>::type load_row(const uint8_t *p)
 {
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
+    if constexpr (PK == 0) {
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
+    } else if constexpr (PK == 4) {
+        typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+        const u32x2_u v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_u *>(p));
+        typename RawPiece<4>::type r = {v.x, v.y};
+        return r;
+    } else {
+        return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
+    }
+}
+
+// a loaded piece as four dwords of one byte per sample
+template <int PK>
+__device__ __forceinline__ u32x4 expand_row(typename RawPiece<PK>::type r)
+{
+    if constexpr (PK == 0) {
+        return r;
+    } else if constexpr (PK == 4) {
+        return unpack_piece<4>(r.x, r.y);
+    } else {
+        return unpack_piece<2>(r, 0u);
+    }
 }
 
 // ---- per-wave LDS buffer of the encoder ------------------------------------------------------
@@ -233,7 +284,7 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
 }
 
 // chunk whose sub-streams outgrew the staging: flush the carried tail, then the global slow path
-template <bool INLINE_SLOW>
+template <bool INLINE_SLOW, int PK>
 __device__ __forceinline__ void overflow_chunk(const uint8_t *src, uint32_t m, const uint2 *lut1, uint32_t *buf,
                                                uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
                                                uint32_t &words, uint32_t &bits)
@@ -242,7 +293,7 @@ __device__ __forceinline__ void overflow_chunk(const uint8_t *src, uint32_t m, c
     MH_WAVE_SYNC();
     dst += pend;
     pend = 0;
-    const uint2 r = INLINE_SLOW ? encode_chunk_slow_body(src, m, lut1, dst, lane) : encode_chunk_slow(src, m, lut1, dst, lane);
+    const uint2 r = INLINE_SLOW ? encode_chunk_slow_body<PK>(src, m, lut1, dst, lane) : encode_chunk_slow<PK>(src, m, lut1, dst, lane);
     words = r.x;
     bits = r.y;
     dst += words;
@@ -317,8 +368,8 @@ __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t 
 // HAS_NEXT is a template constant on purpose: with a run-time flag the refill loads of the second half
 // sit in a branch, the compiler's wait-count pass cannot count them, and every vmcnt in that half
 // tightens by one per row down to vmcnt(0) -- the wave then drains its whole window at each chunk end.
-template <int LC, int PB, int ABL, bool HAS_NEXT>
-__device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_t *__restrict__ cur,
+template <int LC, int PB, int ABL, bool HAS_NEXT, int PK>
+__device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&v)[kWin], const uint8_t *__restrict__ cur,
                                                   const uint2 *lut2, const uint2 *lut1,
                                                   uint32_t *buf, uint32_t cap, uint32_t *__restrict__ &dst,
                                                   uint32_t &pend, int lane, uint32_t &words, uint32_t &bits)
@@ -336,9 +387,9 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
     }
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
-        u32x4 x = v[k & (kWin - 1)];
+        u32x4 x = expand_row<PK>(v[k & (kWin - 1)]);
         if (k < kRows - kWin || HAS_NEXT)
-            v[k & (kWin - 1)] = load_row(cur + ((uint32_t)(k + kWin) * kLanes + lane) * MH_PIECE);
+            v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
         if (ABL == 4) {
             acc += x.x ^ x.y ^ x.z ^ x.w;
             continue;
@@ -400,7 +451,7 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
     }
     MH_WAVE_SYNC();
     if (__any(sp > cap)) {
-        overflow_chunk<false>(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
+        overflow_chunk<false, PK>(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
         return;
     }
     merge_and_flush<(LC == 0 ? 4 : 8), ABL>(buf, cap, tot, sp, dst, pend, lane, words, bits);
@@ -411,7 +462,7 @@ __device__ __forceinline__ void encode_full_chunk(u32x4 (&v)[kWin], const uint8_
 // and only the one cut piece (m % 16 samples, in lane (m / 16) % 64, that lane's last piece) goes
 // symbol by symbol.  Same staging and the same in-place merge.
 // Returns {words, bits, new pend, words by which dst advanced}.
-template <int LC, int PB>
+template <int LC, int PB, int PK>
 __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ src, uint32_t m, const uint2 *lut2,
                                                    const uint2 *lut1, uint32_t *buf, uint32_t cap,
                                                    uint32_t *__restrict__ dst0, uint32_t pend, int lane)
@@ -427,26 +478,24 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         if ((uint32_t)(half * 8) >= nrows) break;
-        u32x4 v[8];
+        typename RawPiece<PK>::type v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const uint32_t piece = (uint32_t)(half * 8 + r) * kLanes + lane;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            v[r] = z;
-            if (piece < nfp) v[r] = load_row(src + piece * MH_PIECE);
+            v[r] = typename RawPiece<PK>::type{};
+            if (piece < nfp) v[r] = load_row<PK>(src + piece * piece_bytes<PK>());
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const uint32_t k = (uint32_t)(half * 8 + r);
             if (k < nrows && k * kLanes + lane < nfp)  // the escapes inside ballot the active lanes only
-                encode_row<LC, PB, 0>(v[r], lut2, acc, nb, sp, st, cap);
+                encode_row<LC, PB, 0>(expand_row<PK>(v[r]), lut2, acc, nb, sp, st, cap);
         }
     }
     const uint32_t cnt = m & 15u;
     if (cnt && (uint32_t)lane == (nfp & 63u)) {  // the cut piece
-        const uint8_t *q = src + nfp * MH_PIECE;
         for (uint32_t i = 0; i < cnt; ++i) {
-            uint32_t b = q[i];
+            uint32_t b = sample_at<PK>(src, nfp * MH_PIECE + i);
             b = b > 15u ? 15u : b;
             const uint2 e = lut1[b];
             acc |= (uint64_t)e.x << nb;
@@ -466,7 +515,7 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
     }
     MH_WAVE_SYNC();
     if (__any(sp > cap))
-        overflow_chunk<true>(src, m, lut1, buf, dst, pend, lane, words, bits);
+        overflow_chunk<true, PK>(src, m, lut1, buf, dst, pend, lane, words, bits);
     else
         merge_and_flush<NE, 0>(buf, cap, tot, sp, dst, pend, lane, words, bits);
     return make_uint4(words, bits, pend, (uint32_t)(dst - dst0));
@@ -475,11 +524,12 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
 // One segment, one wave: the chunks of segment `seg` of channel `ch` through the wave's tables
 // (lut2 pair table, lut1 single-symbol table) and its staging buffer.
 // the first kWin rows of a segment that starts with a full chunk
-__device__ __forceinline__ void load_first_rows(u32x4 (&v)[kWin], const uint8_t *src, int lane)
+template <int PK>
+__device__ __forceinline__ void load_first_rows(typename RawPiece<PK>::type (&v)[kWin], const uint8_t *src, int lane)
 {
 #pragma unroll
     for (int k = 0; k < kWin; ++k) {
-        v[k] = load_row(src + ((uint32_t)k * kLanes + lane) * MH_PIECE);
+        v[k] = load_row<PK>(src + ((uint32_t)k * kLanes + lane) * piece_bytes<PK>());
         asm volatile("" ::: "memory");  // keep the rows in issue order: vmcnt retires in order
     }
 }
@@ -487,9 +537,9 @@ __device__ __forceinline__ void load_first_rows(u32x4 (&v)[kWin], const uint8_t 
 // src = first sample, n = samples, out = the segment's slot.  PRE: the caller has already issued
 // load_first_rows into v (when n >= one chunk) -- the per-wave-table kernel does so before it builds
 // its tables, so that the rows are in flight while the table entries are computed.
-template <int LC, int PB, int ABL, bool PRE>
+template <int LC, int PB, int ABL, bool PRE, int PK>
 __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, uint32_t ch, const uint8_t *src, uint64_t n,
-                                               uint32_t *__restrict__ out, u32x4 (&v)[kWin], const uint2 *lut2,
+                                               uint32_t *__restrict__ out, typename RawPiece<PK>::type (&v)[kWin], const uint2 *lut2,
                                                const uint2 *lut1, uint32_t *buf, uint32_t cap, int lane,
                                                uint64_t &seg_bits)
 {
@@ -498,21 +548,22 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
     const uint32_t rem = (uint32_t)(n % kChunk);
     uint64_t words = 0, bits = 0;
     if (nfull) {
-        if (!PRE) load_first_rows(v, src, lane);
+        constexpr size_t kChunkBytes = (size_t)(kChunk / MH_PIECE) * piece_bytes<PK>();
+        if (!PRE) load_first_rows<PK>(v, src, lane);
         uint32_t w, b;
         for (uint32_t c = 0; c + 1 < nfull; ++c) {
-            encode_full_chunk<LC, PB, ABL, true>(v, src + (size_t)c * kChunk, lut2, lut1, buf, cap, out, pend, lane, w, b);
+            encode_full_chunk<LC, PB, ABL, true, PK>(v, src + (size_t)c * kChunkBytes, lut2, lut1, buf, cap, out, pend, lane, w, b);
             words += w;
             bits += b;
         }
-        encode_full_chunk<LC, PB, ABL, false>(v, src + (size_t)(nfull - 1) * kChunk, lut2, lut1, buf, cap, out, pend, lane,
-                                              w, b);
+        encode_full_chunk<LC, PB, ABL, false, PK>(v, src + (size_t)(nfull - 1) * kChunkBytes, lut2, lut1, buf, cap, out, pend,
+                                                  lane, w, b);
         words += w;
         bits += b;
     }
     if (rem) {
-        const uint4 r = encode_partial_chunk<LC, PB>(src + (size_t)nfull * kChunk, rem, lut2, lut1, buf, cap, out, pend,
-                                                      lane);
+        const uint4 r = encode_partial_chunk<LC, PB, PK>(src + (size_t)nfull * (kChunk / MH_PIECE) * piece_bytes<PK>(), rem, lut2,
+                                                          lut1, buf, cap, out, pend, lane);
         words += r.x;
         bits += r.y;
         pend = r.z;
@@ -527,7 +578,11 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
 }
 
 // Long channels: a workgroup owns up to 4 consecutive segments OF ONE CHANNEL and shares its tables.
-template <int LC, int PB, int ABL = 0>
+// Byte offset of sample t (a multiple of 16) in a channel stream of packing PK
+template <int PK>
+__device__ __forceinline__ uint64_t stream_bytes(uint64_t t) { return PK == 0 ? t : (t >> 4) * piece_bytes<PK>(); }
+
+template <int LC, int PB, int ABL = 0, int PK = 0>
 __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -554,10 +609,12 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     const uint32_t cap = a.e.stage_dw;
     uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
     const uint32_t seg = seg0 + (uint32_t)wave;
-    u32x4 v[kWin];
+    typename RawPiece<PK>::type v[kWin];
     uint64_t bits;
-    encode_segment<LC, PB, ABL, false>(a.e, seg, ch, a.e.data + a.e.ch_off[ch] + a.e.w0[ch] + a.e.seg_first[seg],
-                                       a.e.seg_n[seg], a.e.payload + a.e.seg_off[seg], v, lut2, lut1, buf, cap, lane, bits);
+    // (packed input exists for whole-channel windows only: w0 = 0 and segments start at chunk boundaries)
+    encode_segment<LC, PB, ABL, false, PK>(a.e, seg, ch,
+                                           a.e.data + a.e.ch_off[ch] + stream_bytes<PK>(a.e.w0[ch] + a.e.seg_first[seg]),
+                                           a.e.seg_n[seg], a.e.payload + a.e.seg_off[seg], v, lut2, lut1, buf, cap, lane, bits);
 }
 
 // Short channels (the reference's real recordings at 50 ms bins are 2e4-7e4 samples per channel,
@@ -567,7 +624,7 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
 // chain of dependent loads, and the segment's first rows are requested before the tables are built.
 __host__ __device__ inline uint32_t enc2w_wave_dwords(uint32_t stage_dw) { return kEncSharedDw + enc2_wave_dwords(stage_dw); }
 
-template <int LC, int PB>
+template <int LC, int PB, int PK = 0>
 __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -579,14 +636,14 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
     uint32_t *wbase = smem + (size_t)wave * enc2w_wave_dwords(cap);
     uint2 *lut2 = reinterpret_cast<uint2 *>(wbase);
     uint2 *lut1 = reinterpret_cast<uint2 *>(wbase + 512);
-    const uint8_t *src = a.e.data + t.src_off;
-    u32x4 v[kWin];
+    const uint8_t *src = a.e.data + t.src_off;  // the planner's records hold byte offsets of the plan's input packing
+    typename RawPiece<PK>::type v[kWin];
     uint2 el = make_uint2(0u, 0u);  // the 16 single-symbol entries {bit-reversed code, length}, one per lane
     if (a.e.cal_mode == 0) {
         if (lane < kLut) el = a.e.lut[(size_t)t.ch * kLut + lane];
-        if (t.n >= (uint32_t)kChunk) load_first_rows(v, src, lane);  // in flight during the table build
+        if (t.n >= (uint32_t)kChunk) load_first_rows<PK>(v, src, lane);  // in flight during the table build
     } else {
-        if (t.n >= (uint32_t)kChunk) load_first_rows(v, src, lane);
+        if (t.n >= (uint32_t)kChunk) load_first_rows<PK>(v, src, lane);
         const int S = (int)a.e.S;
         int p;
         uint32_t k;
@@ -623,8 +680,8 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
     MH_WAVE_SYNC();
     uint64_t bits = 0;
     if (t.n)
-        encode_segment<LC, PB, 0, true>(a.e, t.seg, t.ch, src, t.n, a.e.payload + t.dst_off, v, lut2, lut1,
-                                        wbase + kEncSharedDw, cap, lane, bits);
+        encode_segment<LC, PB, 0, true, PK>(a.e, t.seg, t.ch, src, t.n, a.e.payload + t.dst_off, v, lut2, lut1,
+                                            wbase + kEncSharedDw, cap, lane, bits);
     if (a.e.cal_mode != 0 && lane == 0) {
         // Bit total of the channel without a zeroing launch: every record adds {bits << 24 | 1} to the
         // channel's word in plan scratch with ONE returning device-scope atomic.  The record that sees

@@ -210,6 +210,63 @@ __global__ __launch_bounds__(256) void k_rebin3(const uint8_t *__restrict__ data
 //   VGPRs and the occupancy that hides more).
 constexpr int kTr2T = 256, kTr2C = 128;
 
+// ---- packed pieces: the intermediate of the time-major (stream) path ----------------------------
+// A piece = 16 consecutive samples of one channel.  The stream encoder clips at S-1 <= 9 anyway, so
+// the de-interleaver may hand it min(x, 15) in 4 bits per sample -- or min(x, 3) in 2 bits when
+// S <= 4 -- and halve / quarter the intermediate's trip through HBM.  Layout, chosen so that the
+// encoder gets its four byte-per-sample dwords back with one shift and one mask each:
+//   4 bits:  dword0 byte j = s[j] | s[j+4] << 4,  dword1 byte j = s[8+j] | s[12+j] << 4
+//   2 bits:  dword  byte j = s[j] | s[j+4] << 2 | s[j+8] << 4 | s[j+12] << 6
+__device__ __forceinline__ uint32_t clip_bytes(uint32_t d, uint32_t lim)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t b = (d >> (8 * i)) & 0xFFu;
+        b = b > lim ? lim : b;
+        r |= b << (8 * i);
+    }
+    return r;
+}
+
+template <int PK>
+__device__ __forceinline__ void pack_piece(u32x4 o, uint32_t &p0, uint32_t &p1)
+{
+    constexpr uint32_t lim = (1u << PK) - 1u;
+    constexpr uint32_t hi = 0x01010101u * (0xFFu & ~lim);
+    if ((o.x | o.y | o.z | o.w) & hi) {  // rare: a count above the field's range
+        o.x = clip_bytes(o.x, lim);
+        o.y = clip_bytes(o.y, lim);
+        o.z = clip_bytes(o.z, lim);
+        o.w = clip_bytes(o.w, lim);
+    }
+    if (PK == 4) {
+        p0 = o.x | (o.y << 4);
+        p1 = o.z | (o.w << 4);
+    } else {
+        p0 = o.x | (o.y << 2) | (o.z << 4) | (o.w << 6);
+        p1 = 0;
+    }
+}
+
+template <int PK>
+__device__ __forceinline__ u32x4 unpack_piece(uint32_t p0, uint32_t p1)
+{
+    u32x4 x;
+    if (PK == 4) {
+        x.x = p0 & 0x0F0F0F0Fu;
+        x.y = (p0 >> 4) & 0x0F0F0F0Fu;
+        x.z = p1 & 0x0F0F0F0Fu;
+        x.w = (p1 >> 4) & 0x0F0F0F0Fu;
+    } else {
+        x.x = p0 & 0x03030303u;
+        x.y = (p0 >> 2) & 0x03030303u;
+        x.z = (p0 >> 4) & 0x03030303u;
+        x.w = (p0 >> 6) & 0x03030303u;
+    }
+    return x;
+}
+
 // ragged-edge helpers of k_deinterleave2, kept out of line so the hot path's register
 // allocation is not shaped by them
 __device__ __noinline__ u32x4 tr2_load_partial(const uint8_t *src, uint32_t n)
@@ -228,6 +285,9 @@ __device__ __noinline__ void tr2_store_partial(uint8_t *dst, u32x4 o, uint32_t n
 
 __device__ __forceinline__ uint32_t tr2_swz(uint32_t row) { return (((row >> 4) & 15u) << 1) ^ (row & 3u); }
 
+// PK = 0: bytes out (channel c = T bytes at out + out_off[c]); PK = 4 / 2: packed pieces out
+// (channel c = ceil(T / 16) pieces of 8 / 4 bytes at out + out_off[c]; a cut last piece is zero-padded)
+template <int PK>
 __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict__ in, uint64_t T, uint32_t C,
                                                        uint32_t tpw, uint8_t *__restrict__ out,
                                                        const uint64_t *out_off)
@@ -299,11 +359,24 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t c = cg * 4 + k;
                     if (c >= cw) break;
-                    uint8_t *dst = out + out_off[c0 + c] + t0 + tb * 16;
-                    if (whole) {
-                        __builtin_nontemporal_store(o[k], reinterpret_cast<u32x4_u *>(dst));
-                    } else {
-                        tr2_store_partial(dst, o[k], th - tb * 16);
+                    if (PK == 0) {
+                        uint8_t *dst = out + out_off[c0 + c] + t0 + tb * 16;
+                        if (whole) {
+                            __builtin_nontemporal_store(o[k], reinterpret_cast<u32x4_u *>(dst));
+                        } else {
+                            tr2_store_partial(dst, o[k], th - tb * 16);
+                        }
+                    } else {  // rows past th were loaded as zeros: a cut piece is zero-padded
+                        uint32_t p0, p1;
+                        pack_piece<(PK ? PK : 4)>(o[k], p0, p1);
+                        uint8_t *dst = out + out_off[c0 + c] + ((t0 >> 4) + tb) * (PK == 4 ? 8 : 4);
+                        if (PK == 4) {
+                            typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+                            const u32x2_u pv = {p0, p1};
+                            __builtin_nontemporal_store(pv, reinterpret_cast<u32x2_u *>(dst));
+                        } else {
+                            __builtin_nontemporal_store(p0, reinterpret_cast<uint32_t *>(dst));
+                        }
                     }
                 }
             }

@@ -194,22 +194,22 @@ static int prepare_kernel(const void *kern, size_t lds, bool needs_lds_base_0)
     return MH_OK;
 }
 
-template <int LC, int PB, int ABL = 0>
+template <int LC, int PB, int ABL = 0, int PK = 0>
 static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 {
     const size_t lds = ((size_t)mh::kEncSharedDw + 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw)) * sizeof(uint32_t);
-    auto kern = mh::k_encode2<LC, PB, ABL>;
+    auto kern = mh::k_encode2<LC, PB, ABL, PK>;
     if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
     hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }
 
-template <int LC, int PB>
+template <int LC, int PB, int PK = 0>
 static int launch_encode2w(const mh::Enc2Args &a, hipStream_t st)
 {
     const size_t lds = 4 * (size_t)mh::enc2w_wave_dwords(a.e.stage_dw) * sizeof(uint32_t);
-    auto kern = mh::k_encode2w<LC, PB>;
+    auto kern = mh::k_encode2w<LC, PB, PK>;
     if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
     hipLaunchKernelGGL(kern, dim3((a.t.ntask + 3) / 4), dim3(256), lds, st, a);
     MH_HIP(hipGetLastError());
@@ -239,10 +239,34 @@ static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st
 // S <= 10 stays well below that).  Chunks that outgrow it take the two-pass global slow path.
 static inline uint32_t enc_stage_dw(uint32_t maxlen) { return 8 * maxlen < 32 ? 8 * maxlen : 32; }
 
+// packed input (time-major path): the same kernels reading 4-bit resp. 2-bit pieces
+template <int PK>
+static int dispatch_encode_packed(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t st)
+{
+    const uint32_t L = p->h.info.maxlen;
+    const bool pb3 = p->h.info.S <= 8;
+    if (PK == 2) {  // S <= 4 only: maxlen <= 3, 3-bit pair packing
+        if (p->h.use_wave_tasks) return L <= 2 ? launch_encode2w<0, 3, 2>(a2, st) : launch_encode2w<1, 3, 2>(a2, st);
+        return L <= 2 ? launch_encode2<0, 3, 0, 2>(a2, st) : launch_encode2<1, 3, 0, 2>(a2, st);
+    }
+    if (p->h.use_wave_tasks) {
+        if (L <= 2) return pb3 ? launch_encode2w<0, 3, 4>(a2, st) : launch_encode2w<0, 4, 4>(a2, st);
+        if (L <= 4) return pb3 ? launch_encode2w<1, 3, 4>(a2, st) : launch_encode2w<1, 4, 4>(a2, st);
+        if (L <= 8) return pb3 ? launch_encode2w<2, 3, 4>(a2, st) : launch_encode2w<2, 4, 4>(a2, st);
+        return launch_encode2w<3, 4, 4>(a2, st);
+    }
+    if (L <= 2) return pb3 ? launch_encode2<0, 3, 0, 4>(a2, st) : launch_encode2<0, 4, 0, 4>(a2, st);
+    if (L <= 4) return pb3 ? launch_encode2<1, 3, 0, 4>(a2, st) : launch_encode2<1, 4, 0, 4>(a2, st);
+    if (L <= 8) return pb3 ? launch_encode2<2, 3, 0, 4>(a2, st) : launch_encode2<2, 4, 0, 4>(a2, st);
+    return launch_encode2<3, 4, 0, 4>(a2, st);
+}
+
 static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t st)
 {
     const uint32_t L = p->h.info.maxlen;
     const bool pb3 = p->h.info.S <= 8;  // 3-bit pair packing when every symbol fits 3 bits
+    if (p->h.input_bits == 4) return dispatch_encode_packed<4>(p, a2, st);
+    if (p->h.input_bits == 2) return dispatch_encode_packed<2>(p, a2, st);
     if (p->h.use_wave_tasks) {
         if (L <= 2) return pb3 ? launch_encode2w<0, 3>(a2, st) : launch_encode2w<0, 4>(a2, st);
         if (L <= 4) return pb3 ? launch_encode2w<1, 3>(a2, st) : launch_encode2w<1, 4>(a2, st);
@@ -422,8 +446,20 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
                    uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
                    uint32_t K, uint32_t seg_chunks)
 {
+    return mh_plan_create_packed(plan, ch_off, ch_len, C, S, h, mode, window, sclv, K, seg_chunks, 8);
+}
+
+int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                          uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
+                          uint32_t K, uint32_t seg_chunks, uint32_t input_bits)
+{
     if (!plan || !ch_off || !ch_len || !sclv) return fail(MH_ERR_ARG, "mh_plan_create: NULL argument");
     *plan = nullptr;
+    if (input_bits != 8 && input_bits != 4 && input_bits != 2)
+        return fail(MH_ERR_ARG, "input_bits=%u (8, 4 or 2)", input_bits);
+    if (input_bits != 8 && window != MH_WIN_FULL)
+        return fail(MH_ERR_ARG, "packed input needs the whole-channel window (MH_WIN_FULL)");
+    if (input_bits == 2 && S > 4) return fail(MH_ERR_ARG, "2-bit input holds symbols 0..3: S=%u is above 4", S);
     mh_plan_info_t I;
     if (int rc = plan_args(ch_len, C, S, h, mode, window, sclv, K, seg_chunks, &I)) return rc;
     int ndev = 0, dev = 0;
@@ -434,6 +470,7 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
     if (!p) return fail(MH_ERR_ARG, "out of host memory");
     p->device = dev;
     p->h.info = I;
+    p->h.input_bits = input_bits;
     mh::plan_host_build(p->h, ch_off, ch_len, sclv, plan_tuning());
     if (p->h.seg_ch.size() > 0xFFFFFFF0ull) {  // segment and task indices are 32-bit on the device
         mh_plan_destroy(p);
@@ -473,6 +510,7 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
                uint8_t *skipped, void *stream)
 {
     if (!p || !data) return fail(MH_ERR_ARG, "mh_measure: NULL argument");
+    if (p->h.input_bits != 8) return fail(MH_ERR_ARG, "mh_measure: this plan reads packed pieces (mh_encode_preset only)");
     if (int rc_ = check_device(p->device, "mh_measure")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
@@ -579,6 +617,7 @@ int mh_encode(mh_plan *p, const uint8_t *data, uint32_t *payload, uint64_t paylo
 {
     if (!p || !data || !payload || !seg_words || !ch_bits)
         return fail(MH_ERR_ARG, "mh_encode: NULL argument");
+    if (p->h.input_bits != 8) return fail(MH_ERR_ARG, "mh_encode: this plan reads packed pieces (mh_encode_preset only)");
     if (int rc_ = check_device(p->device, "mh_encode")) return rc_;
     if (payload_cap_words < p->h.info.payload_cap_words)
         return fail(MH_ERR_CAPACITY, "payload buffer holds %llu words, plan needs %llu",
@@ -857,8 +896,29 @@ int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, con
     if (bx > 0x7FFFFFFFull) bx = 0x7FFFFFFFull;
     const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
     if (by > 65535) return fail(MH_ERR_ARG, "mh_deinterleave: C=%u too large", C);
-    hipLaunchKernelGGL(mh::k_deinterleave2, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+    hipLaunchKernelGGL(mh::k_deinterleave2<0>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
                        out, out_off);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t bits, uint8_t *out,
+                           const uint64_t *out_off, void *stream)
+{
+    if (!in || !out || !out_off || C == 0) return fail(MH_ERR_ARG, "mh_deinterleave_packed: bad argument");
+    if (bits != 4 && bits != 2) return fail(MH_ERR_ARG, "mh_deinterleave_packed: bits=%u (4 or 2)", bits);
+    if (T == 0) return MH_OK;
+    const uint32_t tpw = 4;
+    uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
+    if (bx > 0x7FFFFFFFull) bx = 0x7FFFFFFFull;
+    const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
+    if (by > 65535) return fail(MH_ERR_ARG, "mh_deinterleave_packed: C=%u too large", C);
+    if (bits == 4)
+        hipLaunchKernelGGL(mh::k_deinterleave2<4>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                           out, out_off);
+    else
+        hipLaunchKernelGGL(mh::k_deinterleave2<2>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                           out, out_off);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }

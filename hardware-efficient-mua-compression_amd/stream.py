@@ -5,8 +5,12 @@ phase fills, per channel, a RAM word {most frequent spike rate, selected encoder
 (RAM.v:4); in the COMPRESSION phase every later bin of every channel, arriving time-major
 |CH1|CH2|...|CHN| per time step (README.md:31), is mapped and encoded with that fixed word.
 `StreamEncoder` is the same protocol on the GPU: calibrate() on the first block, then
-encode_block() on each later block -- de-interleave (mh_deinterleave) + encode with the
-preset word (mh_encode_preset), no recalibration.
+encode_block() on each later block -- de-interleave + encode with the preset word
+(mh_encode_preset), no recalibration.  The channel-major intermediate between the two kernels
+is PACKED: the encoder clips at S-1 anyway, so the de-interleaver writes min(x, 15) in 4 bits
+per sample -- min(x, 3) in 2 bits when S <= 4 -- (mh_deinterleave_packed) and the encoder reads
+those pieces directly; the intermediate's round trip through HBM shrinks from 2 x 1 byte per
+sample to 2 x 1/2 resp. 2 x 1/4.
 """
 import numpy as np
 import torch
@@ -43,9 +47,12 @@ class StreamEncoder:
         per block."""
         slot = self._slots.get(Tb)
         if slot is None:
-            cs = ChannelSet.empty([Tb] * self.C, device=self.device)
+            bits = 2 if self.S <= 4 else 4
+            # packed layout: ceil(Tb / 16) pieces of 16 * bits / 8 bytes per channel
+            packed = ChannelSet.empty([(Tb + 15) // 16 * 2 * bits] * self.C, device=self.device)
+            cs = ChannelSet(packed.data, packed.ch_off, np.full(self.C, Tb, np.uint64))  # lengths in samples
             plan = codec.Plan(cs.ch_off, cs.ch_len, self.S, 0, self.mode, WIN_FULL, self.sclv,
-                              seg_chunks=self.seg_chunks)
+                              seg_chunks=self.seg_chunks, input_bits=bits)
             e = plan.alloc_encoded()
             # the block's Encoded record points at the stored RAM word: nothing to copy per block
             e = codec.Encoded(e.payload, e.seg_words, e.ch_bits, self.peak, self.enc, e.skipped, e.seg_off, e.dense)
@@ -77,9 +84,10 @@ class StreamEncoder:
             raise ValueError("block has %d channels, encoder was built for %d" % (C, self.C))
         slot = self._slot(Tb)
         cs, plan = slot["cs"], slot["plan"]
-        _lib.check(_lib.lib().mh_deinterleave(ct.c_void_p(t.data_ptr()), Tb, C, ct.c_void_p(cs.data.data_ptr()),
-                                              ct.c_void_p(slot["d_off"].data_ptr()),
-                                              ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        _lib.check(_lib.lib().mh_deinterleave_packed(ct.c_void_p(t.data_ptr()), Tb, C, plan.input_bits,
+                                                     ct.c_void_p(cs.data.data_ptr()),
+                                                     ct.c_void_p(slot["d_off"].data_ptr()),
+                                                     ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
         enc = slot["enc"]
         _lib.check(_lib.lib().mh_encode_preset(plan._h, ct.c_void_p(cs.data.data_ptr()), ct.c_void_p(self.peak.data_ptr()),
                                                ct.c_void_p(self.enc.data_ptr()), ct.c_void_p(enc.payload.data_ptr()),

@@ -108,6 +108,15 @@ int mh_approx_sort_perm(int S, int peak, uint8_t *idx);
 int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
                    uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
                    uint32_t K, uint32_t seg_chunks);
+/* The same for a PACKED input buffer, the intermediate of the time-major (implant-order) path:
+ * input_bits = 4 or 2 means channel i is ceil(ch_len[i] / 16) pieces of 8 resp. 4 bytes at ch_off[i]
+ * (bytes), as mh_deinterleave_packed writes them; input_bits = 8 is mh_plan_create.  Packed plans
+ * cover whole channels (MH_WIN_FULL), 2-bit ones need S <= 4, and only mh_encode_preset reads
+ * them (a calibrate-then-stream encoder has its (peak, encoder) word already); mh_decode on such a
+ * plan writes ordinary bytes. */
+int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
+                          uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
+                          uint32_t K, uint32_t seg_chunks, uint32_t input_bits);
 int mh_plan_destroy(mh_plan *plan);
 int mh_plan_info(const mh_plan *plan, mh_plan_info_t *info);
 /* host copies of the segment directory (each array n_segments long, any may be NULL):
@@ -211,6 +220,14 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
  * Channel c is written to out + out_off[c] (T bytes).  in, out, out_off: device. */
 int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, const uint64_t *out_off,
                     void *stream);
+/* The same transposition with the output clipped and packed: min(x, 15) in 4 bits per sample
+ * (bits = 4) or min(x, 3) in 2 bits (bits = 2; enough when S <= 4).  The stream encoder clips at
+ * S-1 anyway, so this halves / quarters the intermediate's trip through HBM.  Channel c is written
+ * as ceil(T / 16) pieces of 8 / 4 bytes at out + out_off[c] (a cut last piece is zero-padded):
+ *   4 bits: dword0 byte j = s[j] | s[j+4] << 4, dword1 byte j = s[8+j] | s[12+j] << 4
+ *   2 bits: dword  byte j = s[j] | s[j+4] << 2 | s[j+8] << 4 | s[j+12] << 6        (j = 0..3) */
+int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t bits, uint8_t *out,
+                           const uint64_t *out_off, void *stream);
 /* The inverse: channel c = T bytes at in + in_off[c]  ->  out[t*C + c] (what a decoder hands back
  * to a consumer of the implant-order stream).  in, in_off, out: device. */
 int mh_interleave(const uint8_t *in, const uint64_t *in_off, uint64_t T, uint32_t C, uint8_t *out,

@@ -87,7 +87,7 @@ int main()
                 CHECK(t.seg < n && !seen[t.seg]);
                 seen[t.seg] = 1;
                 CHECK(t.ch == p.seg_ch[t.seg] && t.n == p.seg_n[t.seg] && t.dst_off == p.seg_off[t.seg]);
-                CHECK(t.src_off == off[t.ch] + p.w0[t.ch] + p.seg_first[t.seg]);
+                CHECK(t.src_off == off[t.ch] + p.w0[t.ch] + p.seg_first[t.seg]);  // byte input
                 CHECK(t.src_off + t.n <= off[t.ch] + len[t.ch]);
                 CHECK((t.flags & 1u) == (p.seg_first[t.seg] == 0 ? 1u : 0u));
                 if (i) CHECK(p.wave_tasks[i - 1].n >= t.n);

@@ -524,6 +524,66 @@ def test_calibrate_then_stream_protocol(mh):
             assert int(c.ch_bits[ch]) == int(lens.sum()), ch
 
 
+@pytest.mark.parametrize("bits", [4, 2])
+def test_packed_deinterleave_layout(mh, bits):
+    """mh_deinterleave_packed against the layout include/muahuff.h documents, ragged T and C, counts
+    far above the field's range (clipped, like the encoder clips at S-1)."""
+    import ctypes as ct
+    rng = np.random.RandomState(bits)
+    lim = (1 << bits) - 1
+    for T, C in ((1, 1), (16, 3), (17, 5), (255, 128), (1000, 96), (4097, 130), (20000, 257)):
+        x = rng.randint(0, 6, size=(T, C)).astype(np.uint8)
+        x[rng.random_sample((T, C)) < 0.02] = 200
+        npiece = (T + 15) // 16
+        pb = 2 * bits                                          # bytes per piece
+        off = (np.arange(C, dtype=np.int64) * ((npiece * pb + 15) // 16 * 16))
+        out = torch.full((int(off[-1]) + npiece * pb + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        d_in = torch.from_numpy(x).cuda()
+        d_off = torch.from_numpy(off).cuda()
+        mh._lib.check(mh._lib.lib().mh_deinterleave_packed(ct.c_void_p(d_in.data_ptr()), T, C, bits, ct.c_void_p(out.data_ptr()),
+                                                           ct.c_void_p(d_off.data_ptr()), None))
+        got = out.cpu().numpy()
+        s = np.zeros((C, npiece * 16), np.uint32)
+        s[:, :T] = np.minimum(x.T, lim)
+        s = s.reshape(C, npiece, 16)
+        if bits == 4:  # dword0 byte j = s[j] | s[j+4] << 4, dword1 byte j = s[8+j] | s[12+j] << 4
+            by = np.concatenate([s[:, :, 0:4] | (s[:, :, 4:8] << 4), s[:, :, 8:12] | (s[:, :, 12:16] << 4)], axis=2)
+        else:          # byte j = s[j] | s[j+4] << 2 | s[j+8] << 4 | s[j+12] << 6
+            by = s[:, :, 0:4] | (s[:, :, 4:8] << 2) | (s[:, :, 8:12] << 4) | (s[:, :, 12:16] << 6)
+        want = by.astype(np.uint8).reshape(C, npiece * pb)
+        for c in range(C):
+            assert np.array_equal(got[off[c]:off[c] + npiece * pb], want[c]), (T, C, c)
+        assert (got[int(off[-1]) + npiece * pb:] == 0xEE).all()
+
+
+@pytest.mark.parametrize("S", [3, 4, 5, 10])
+def test_stream_blocks_through_the_packed_intermediate(mh, S):
+    """Time-major blocks -> packed pieces (2 bits for S <= 4, else 4) -> preset encode: every block
+    decodes to min(x, S-1) and costs exactly the code lengths of its symbols; long blocks (shared-table
+    kernels), short ones (wave tasks), ragged lengths, counts up to 255."""
+    from muahuff import stream
+    rng = np.random.RandomState(100 + S)
+    C = 70
+    tab = helpers.sclv_tables()[S]
+    rates = np.exp(rng.uniform(np.log(0.05), np.log(3.0), size=C))
+
+    def block(T):
+        x = np.minimum(rng.poisson(rates, size=(T, C)), 255).astype(np.uint8)
+        x[rng.random_sample((T, C)) < 0.01] = rng.randint(4, 256)
+        return x
+    se = stream.StreamEncoder(C, S, 6, tab)
+    peak, enc = se.calibrate(block(64))
+    peak, enc = peak.cpu().numpy(), enc.cpu().numpy()
+    for T in (16384 * 9 + 5, 16384 * 2, 16383, 100, 17, 16, 1):
+        x = block(T)
+        c = se.encode_block(x)
+        assert np.array_equal(stream.StreamEncoder.decode_block(c), np.minimum(x, S - 1)), T
+        for ch in range(0, C, 7):
+            rank_of = np.argsort(OC.approx_sort_rule(S, int(peak[ch])))
+            assert int(c.ch_bits[ch]) == int(tab[enc[ch]][rank_of[np.minimum(x[:, ch], S - 1)]].sum()), (T, ch)
+    se.close()
+
+
 def test_stream_slots_are_reused_and_follow_recalibration(mh):
     """Blocks of two shapes alternate (cached plans and buffers are reused), then the encoder is
     re-calibrated on very different data: later blocks must be coded with the NEW word."""
