@@ -38,7 +38,7 @@ PROTOTYPES = {
     "mh_codebook": (_int, [_vp, _int, _vp, _vp]),
     "mh_approx_sort_perm": (_int, [_int, _int, _vp]),
     "mh_plan_create": (_int, [ct.POINTER(_vp), _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32]),
-    "mh_plan_create_packed": (_int, [ct.POINTER(_vp), _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32]),
+    "mh_plan_create_packed": (_int, [ct.POINTER(_vp), _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u64]),
     "mh_plan_destroy": (_int, [_vp]),
     "mh_plan_info": (_int, [_vp, ct.POINTER(PlanInfo)]),
     "mh_plan_segments": (_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -55,7 +55,7 @@ PROTOTYPES = {
     "mh_synth_poisson": (_int, [_vp, _vp, _vp, _u32, _u64, _vp, _u64, _vp]),
     "mh_rebin": (_int, [_vp, _vp, _vp, _u32, _u64, _u32, _int, _vp, _vp, _vp]),
     "mh_deinterleave": (_int, [_vp, _u64, _u32, _vp, _vp, _vp]),
-    "mh_deinterleave_packed": (_int, [_vp, _u64, _u32, _u32, _vp, _vp, _vp]),
+    "mh_deinterleave_packed": (_int, [_vp, _u64, _u32, _u32, _vp, _vp, _u64, _vp]),
     "mh_interleave": (_int, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "mh_sweep_create": (_int, [ct.POINTER(_vp), _vp, _vp, _u32, _vp, _u32]),
     "mh_sweep_destroy": (_int, [_vp]),

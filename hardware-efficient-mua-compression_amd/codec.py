@@ -56,10 +56,11 @@ class Plan:
     """One design point (S, h, mapper, window rule, K candidate encoders) over one channel
     layout.  Mirrors mh_plan_* of include/muahuff.h."""
 
-    def __init__(self, ch_off, ch_len, S, h, mode, window, sclv, seg_chunks=0, input_bits=8):
+    def __init__(self, ch_off, ch_len, S, h, mode, window, sclv, seg_chunks=0, input_bits=8, chunk_stride=0):
         """seg_chunks: chunks per segment; 0 = the planner's choice (info.seg_chunks tells).
         input_bits: 8 = one byte per sample; 4 / 2 = the packed pieces mh_deinterleave_packed writes
-        (ch_off then counts bytes of the packed buffer; whole-channel window, preset encode only)."""
+        (ch_off then counts bytes of the packed buffer; whole-channel window, preset encode only);
+        chunk_stride != 0: that buffer is chunk-blocked (include/muahuff.h, mh_plan_create_packed)."""
         _need_gpu()
         self.ch_off = np.ascontiguousarray(ch_off, dtype=np.uint64)
         self.ch_len = np.ascontiguousarray(ch_len, dtype=np.uint64)
@@ -70,7 +71,8 @@ class Plan:
         rc = _lib.lib().mh_plan_create_packed(ct.byref(h_), self.ch_off.ctypes.data, self.ch_len.ctypes.data,
                                               len(self.ch_len), int(S), int(h), int(mode), int(window),
                                               self.sclv.ctypes.data, self.sclv.shape[0], int(seg_chunks),
-                                              self.input_bits)
+                                              self.input_bits, int(chunk_stride))
+        self.chunk_stride = int(chunk_stride)
         if rc == _lib.ERR_EMPTY_CHANNEL:
             # the reference fails the same way: functions_1.py:45 indexes data_in[0]
             raise IndexError("index 0 is out of bounds for axis 0 with size 0")

@@ -368,9 +368,11 @@ __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t 
 // HAS_NEXT is a template constant on purpose: with a run-time flag the refill loads of the second half
 // sit in a branch, the compiler's wait-count pass cannot count them, and every vmcnt in that half
 // tightens by one per row down to vmcnt(0) -- the wave then drains its whole window at each chunk end.
+// nxt = first byte of the chunk that follows `cur` in the stream (cur + one chunk in the plain layouts,
+// elsewhere in the chunk-blocked intermediate of the time-major path); only read when HAS_NEXT
 template <int LC, int PB, int ABL, bool HAS_NEXT, int PK>
 __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&v)[kWin], const uint8_t *__restrict__ cur,
-                                                  const uint2 *lut2, const uint2 *lut1,
+                                                  const uint8_t *__restrict__ nxt, const uint2 *lut2, const uint2 *lut1,
                                                   uint32_t *buf, uint32_t cap, uint32_t *__restrict__ &dst,
                                                   uint32_t &pend, int lane, uint32_t &words, uint32_t &bits)
 {
@@ -388,8 +390,10 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         u32x4 x = expand_row<PK>(v[k & (kWin - 1)]);
-        if (k < kRows - kWin || HAS_NEXT)
+        if (k < kRows - kWin)
             v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
+        else if (HAS_NEXT)
+            v[k & (kWin - 1)] = load_row<PK>(nxt + ((uint32_t)(k + kWin - kRows) * kLanes + lane) * piece_bytes<PK>());
         if (ABL == 4) {
             acc += x.x ^ x.y ^ x.z ^ x.w;
             continue;
@@ -547,23 +551,24 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
     const uint32_t nfull = (uint32_t)(n / kChunk);
     const uint32_t rem = (uint32_t)(n % kChunk);
     uint64_t words = 0, bits = 0;
+    // bytes from one chunk of the channel to the next: contiguous, unless the plan says otherwise
+    const size_t cstride = e.chunk_stride ? (size_t)e.chunk_stride : (size_t)(kChunk / MH_PIECE) * piece_bytes<PK>();
     if (nfull) {
-        constexpr size_t kChunkBytes = (size_t)(kChunk / MH_PIECE) * piece_bytes<PK>();
         if (!PRE) load_first_rows<PK>(v, src, lane);
         uint32_t w, b;
         for (uint32_t c = 0; c + 1 < nfull; ++c) {
-            encode_full_chunk<LC, PB, ABL, true, PK>(v, src + (size_t)c * kChunkBytes, lut2, lut1, buf, cap, out, pend, lane, w, b);
+            encode_full_chunk<LC, PB, ABL, true, PK>(v, src + (size_t)c * cstride, src + (size_t)(c + 1) * cstride, lut2, lut1, buf,
+                                                     cap, out, pend, lane, w, b);
             words += w;
             bits += b;
         }
-        encode_full_chunk<LC, PB, ABL, false, PK>(v, src + (size_t)(nfull - 1) * kChunkBytes, lut2, lut1, buf, cap, out, pend,
+        encode_full_chunk<LC, PB, ABL, false, PK>(v, src + (size_t)(nfull - 1) * cstride, src, lut2, lut1, buf, cap, out, pend,
                                                   lane, w, b);
         words += w;
         bits += b;
     }
     if (rem) {
-        const uint4 r = encode_partial_chunk<LC, PB, PK>(src + (size_t)nfull * (kChunk / MH_PIECE) * piece_bytes<PK>(), rem, lut2,
-                                                          lut1, buf, cap, out, pend, lane);
+        const uint4 r = encode_partial_chunk<LC, PB, PK>(src + (size_t)nfull * cstride, rem, lut2, lut1, buf, cap, out, pend, lane);
         words += r.x;
         bits += r.y;
         pend = r.z;
@@ -613,7 +618,9 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     uint64_t bits;
     // (packed input exists for whole-channel windows only: w0 = 0 and segments start at chunk boundaries)
     encode_segment<LC, PB, ABL, false, PK>(a.e, seg, ch,
-                                           a.e.data + a.e.ch_off[ch] + stream_bytes<PK>(a.e.w0[ch] + a.e.seg_first[seg]),
+                                           a.e.data + a.e.ch_off[ch] +
+                                               (a.e.chunk_stride ? ((a.e.w0[ch] + a.e.seg_first[seg]) / kChunk) * a.e.chunk_stride
+                                                                 : stream_bytes<PK>(a.e.w0[ch] + a.e.seg_first[seg])),
                                            a.e.seg_n[seg], a.e.payload + a.e.seg_off[seg], v, lut2, lut1, buf, cap, lane, bits);
 }
 

@@ -289,6 +289,7 @@ struct EncArgs {
     unsigned long long *ch_bits;
     uint32_t nseg;
     uint32_t stage_dw;  // staging dwords per lane = 8 * maxlen (256 samples * maxlen / 32)
+    uint64_t chunk_stride;  // bytes between consecutive 16384-sample chunks of a channel; 0 = contiguous
     // per-wave-table kernel only: where the wave gets its channel's (peak, encoder) word from
     //   0  the LUT that k_calibrate / k_lut_preset wrote (`lut`)
     //   1  calibrates in the wave (window of <= kCalDirect samples) -- mh_encode is one launch

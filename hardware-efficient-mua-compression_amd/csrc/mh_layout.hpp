@@ -287,16 +287,36 @@ __device__ __forceinline__ uint32_t tr2_swz(uint32_t row) { return (((row >> 4) 
 
 // PK = 0: bytes out (channel c = T bytes at out + out_off[c]); PK = 4 / 2: packed pieces out
 // (channel c = ceil(T / 16) pieces of 8 / 4 bytes at out + out_off[c]; a cut last piece is zero-padded)
+// abl (tuning builds pass it; 0 in production): 1 = no global stores, 2 = also no turn (loads + LDS writes only),
+// 3 = loads only
 template <int PK>
 __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict__ in, uint64_t T, uint32_t C,
                                                        uint32_t tpw, uint8_t *__restrict__ out,
-                                                       const uint64_t *out_off)
+                                                       const uint64_t *out_off, uint32_t abl = 0, uint64_t blk_stride = 0)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTr2T * (kTr2C / 4)];
-    const uint32_t c0 = blockIdx.y * kTr2C;
+    // 1-D grid, channel strip fastest: consecutive workgroups -- dealt round-robin over the XCDs, running at
+    // the same time -- take the 128-byte strips of the SAME rows, so every 1 KiB-ish row of the time-major
+    // matrix is consumed while its DRAM page is open.  (Strip-major order walks one strip through all of time
+    // first: each page is then opened once per strip, and the kernel runs at 2.6 TB/s instead of 5+.)
+    const uint32_t nstrip = (C + kTr2C - 1) / kTr2C;
+    const uint32_t c0 = (blockIdx.x % nstrip) * kTr2C;
     const uint32_t cw = C - c0 < (uint32_t)kTr2C ? C - c0 : (uint32_t)kTr2C;
     const uint64_t ntiles = (T + kTr2T - 1) / kTr2T;
-    for (uint64_t tile0 = (uint64_t)blockIdx.x * tpw; tile0 < ntiles; tile0 += (uint64_t)gridDim.x * tpw) {
+    const uint64_t gx = gridDim.x / nstrip;
+    // channel bases of this thread's work items, loaded once: a global load inside the turn would sit
+    // behind the prefetched tile in the in-order memory counter and drain it
+    constexpr int kG = PK == 0 ? 1 : PK == 4 ? 2 : 4;
+    constexpr int kUU = kG == 4 ? 1 : 2 / kG;
+    uint64_t obase[4] = {0, 0, 0, 0};  // (packed modes: one work item per thread and tile)
+    if (PK != 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = (threadIdx.x / (16u / kG)) * 4 + k;
+            obase[k] = c < cw ? out_off[c0 + c] : 0;
+        }
+    }
+    for (uint64_t tile0 = (uint64_t)(blockIdx.x / nstrip) * tpw; tile0 < ntiles; tile0 += gx * tpw) {
         const uint64_t tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
         u32x4 V[8];
         auto fetch = [&](uint64_t tl) {
@@ -317,10 +337,22 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
                 V[j] = v;
             }
         };
+        // PIPE: the next tile's loads are issued before this tile is turned (its registers stay live across
+        // the turn); measured per variant
+        constexpr bool PIPE = PK != 0;
+        if (PIPE) fetch(tile0);
         for (uint64_t tl = tile0; tl < tend; ++tl) {
             const uint64_t t0 = tl * kTr2T;
             const uint32_t th = T - t0 < (uint64_t)kTr2T ? (uint32_t)(T - t0) : (uint32_t)kTr2T;
-            fetch(tl);
+            if (!PIPE) fetch(tl);
+            if (abl == 3) {  // ablation: consume the loads, nothing else
+                uint32_t z = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z ^= V[j].x ^ V[j].y ^ V[j].z ^ V[j].w;
+                if (z == 0x12345678u) out[0] = 1;
+                if (PIPE && tl + 1 < tend) fetch(tl + 1);
+                continue;
+            }
             __syncthreads();  // previous tile fully turned
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -333,49 +365,88 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
                 r[(q4 + 3) ^ sw] = V[j].w;
             }
             __syncthreads();
+            if (PIPE && tl + 1 < tend) fetch(tl + 1);
+            if (abl == 2) continue;
+            // turn: a work item = 4 channels x G blocks of 16 time steps; G = 1 (bytes out), 2 (4-bit) or
+            // 4 (2-bit), so that an item always emits 16 bytes per channel (narrow stores cost several
+            // times a 16-byte store per byte on this part)
+            constexpr int G = PK == 0 ? 1 : PK == 4 ? 2 : 4;
+            constexpr uint32_t NTB = 16 / G;  // items along the tile's 256 time steps
 #pragma unroll 1
-            for (int uu = 0; uu < 2; ++uu) {
-                const uint32_t id = threadIdx.x + 256u * uu, tb = id & 15u, cg = id >> 4;
-                if (cg * 4 >= cw || tb * 16 >= th) continue;
-                uint32_t d[16];
+            for (int uu = 0; uu < kUU; ++uu) {
+                const uint32_t id = threadIdx.x + 256u * uu, tb = id % NTB, cg = id / NTB;
+                if (cg >= (uint32_t)(kTr2C / 4) || cg * 4 >= cw || tb * G * 16 >= th) continue;
+                u32x4 pk[4] = {};  // packed output of the item's 4 channels, filled by shifting pieces in
+#pragma unroll 1
+                for (int g = 0; g < G; ++g) {  // (rolled: the transposition's registers are reused per block)
+                    const uint32_t tbb = tb * G + g;  // 16-step block inside the tile; rows past th hold zeros
+                    uint32_t d[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    d[i] = tile[(tb * 16 + i) * (kTr2C / 4) + (cg ^ (tb << 1) ^ (uint32_t)(i & 3))];
-                u32x4 o[4];
+                    for (int i = 0; i < 16; ++i)
+                        d[i] = tile[(tbb * 16 + i) * (kTr2C / 4) + (cg ^ (tbb << 1) ^ (uint32_t)(i & 3))];
+                    u32x4 o[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {  // rows 4m..4m+3 -> dword m of each channel's 16 bytes
-                    const uint32_t a = d[4 * m], b = d[4 * m + 1], c = d[4 * m + 2], e = d[4 * m + 3];
-                    const uint32_t t0_ = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
-                    const uint32_t t1_ = __builtin_amdgcn_perm(e, c, 0x05010400u);  // c0 e0 c1 e1
-                    const uint32_t t2_ = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
-                    const uint32_t t3_ = __builtin_amdgcn_perm(e, c, 0x07030602u);
-                    o[0][m] = __builtin_amdgcn_perm(t1_, t0_, 0x05040100u);
-                    o[1][m] = __builtin_amdgcn_perm(t1_, t0_, 0x07060302u);
-                    o[2][m] = __builtin_amdgcn_perm(t3_, t2_, 0x05040100u);
-                    o[3][m] = __builtin_amdgcn_perm(t3_, t2_, 0x07060302u);
-                }
-                const bool whole = tb * 16 + 16 <= th;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t c = cg * 4 + k;
-                    if (c >= cw) break;
+                    for (int m = 0; m < 4; ++m) {  // rows 4m..4m+3 -> dword m of each channel's 16 bytes
+                        const uint32_t a = d[4 * m], b = d[4 * m + 1], c = d[4 * m + 2], e = d[4 * m + 3];
+                        const uint32_t t0_ = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+                        const uint32_t t1_ = __builtin_amdgcn_perm(e, c, 0x05010400u);  // c0 e0 c1 e1
+                        const uint32_t t2_ = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+                        const uint32_t t3_ = __builtin_amdgcn_perm(e, c, 0x07030602u);
+                        o[0][m] = __builtin_amdgcn_perm(t1_, t0_, 0x05040100u);
+                        o[1][m] = __builtin_amdgcn_perm(t1_, t0_, 0x07060302u);
+                        o[2][m] = __builtin_amdgcn_perm(t3_, t2_, 0x05040100u);
+                        o[3][m] = __builtin_amdgcn_perm(t3_, t2_, 0x07060302u);
+                    }
                     if (PK == 0) {
-                        uint8_t *dst = out + out_off[c0 + c] + t0 + tb * 16;
-                        if (whole) {
-                            __builtin_nontemporal_store(o[k], reinterpret_cast<u32x4_u *>(dst));
-                        } else {
-                            tr2_store_partial(dst, o[k], th - tb * 16);
+                        const bool whole = tbb * 16 + 16 <= th;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t c = cg * 4 + k;
+                            if (c >= cw) break;
+                            uint8_t *dst = out + out_off[c0 + c] + t0 + tbb * 16;
+                            if (abl == 1) {
+                                if ((o[k].x ^ o[k].y) == 0x12345678u && o[k].z == 77u) dst[0] = 1;
+                            } else if (whole) {
+                                __builtin_nontemporal_store(o[k], reinterpret_cast<u32x4_u *>(dst));
+                            } else {
+                                tr2_store_partial(dst, o[k], th - tbb * 16);
+                            }
                         }
                     } else {  // rows past th were loaded as zeros: a cut piece is zero-padded
-                        uint32_t p0, p1;
-                        pack_piece<(PK ? PK : 4)>(o[k], p0, p1);
-                        uint8_t *dst = out + out_off[c0 + c] + ((t0 >> 4) + tb) * (PK == 4 ? 8 : 4);
-                        if (PK == 4) {
-                            typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
-                            const u32x2_u pv = {p0, p1};
-                            __builtin_nontemporal_store(pv, reinterpret_cast<u32x2_u *>(dst));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            uint32_t p0, p1;
+                            pack_piece<(PK ? PK : 4)>(o[k], p0, p1);
+                            const u32x4 q = pk[k];
+                            if (PK == 4) {
+                                const u32x4 r = {q.z, q.w, p0, p1};
+                                pk[k] = r;
+                            } else {
+                                const u32x4 r = {q.y, q.z, q.w, p0};
+                                pk[k] = r;
+                            }
+                        }
+                    }
+                }
+                if (PK != 0) {  // 16 bytes per channel: G pieces; channel regions are padded to 16 bytes
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t c = cg * 4 + k;
+                        if (c >= cw) break;
+                        const u32x4 pv = pk[k];
+                        // blk_stride != 0: CHUNK-BLOCKED layout -- the 16384-sample chunk j of a channel sits at
+                        // out_off[c] + j * blk_stride, so that one tile's stores stay inside one small region
+                        const uint64_t piece = (t0 >> 4) + (uint64_t)tb * G;  // piece index in the channel
+                        uint8_t *dst = out + obase[k] +
+                                       (blk_stride ? (piece >> 10) * blk_stride + (piece & 1023u) * (PK == 4 ? 8 : 4)
+                                                   : piece * (PK == 4 ? 8 : 4));
+                        if (abl == 1) {
+                            if ((pv.x ^ pv.y) == 0x12345678u && pv.z == 77u) dst[0] = 1;
                         } else {
-                            __builtin_nontemporal_store(p0, reinterpret_cast<uint32_t *>(dst));
+                            // plain, not non-temporal: the workgroup's consecutive tiles extend the same lines of
+                            // this channel, and the XCD's L2 merges them into whole lines before they go out --
+                            // each visit of a channel's stream costs a DRAM row activation whatever it carries
+                            *reinterpret_cast<u32x4_u *>(dst) = pv;
                         }
                     }
                 }
@@ -393,10 +464,16 @@ __global__ __launch_bounds__(256) void k_interleave(const uint8_t *__restrict__ 
                                                     uint8_t *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kTr2T * (kTr2C / 4)];
-    const uint32_t c0 = blockIdx.y * kTr2C;
+    // 1-D grid, channel strip fastest: consecutive workgroups -- dealt round-robin over the XCDs, running at
+    // the same time -- take the 128-byte strips of the SAME rows, so every 1 KiB-ish row of the time-major
+    // matrix is consumed while its DRAM page is open.  (Strip-major order walks one strip through all of time
+    // first: each page is then opened once per strip, and the kernel runs at 2.6 TB/s instead of 5+.)
+    const uint32_t nstrip = (C + kTr2C - 1) / kTr2C;
+    const uint32_t c0 = (blockIdx.x % nstrip) * kTr2C;
     const uint32_t cw = C - c0 < (uint32_t)kTr2C ? C - c0 : (uint32_t)kTr2C;
     const uint64_t ntiles = (T + kTr2T - 1) / kTr2T;
-    for (uint64_t tile0 = (uint64_t)blockIdx.x * tpw; tile0 < ntiles; tile0 += (uint64_t)gridDim.x * tpw) {
+    const uint64_t gx = gridDim.x / nstrip;
+    for (uint64_t tile0 = (uint64_t)(blockIdx.x / nstrip) * tpw; tile0 < ntiles; tile0 += gx * tpw) {
         const uint64_t tend = tile0 + tpw < ntiles ? tile0 + tpw : ntiles;
         for (uint64_t tl = tile0; tl < tend; ++tl) {
             const uint64_t t0 = tl * kTr2T;

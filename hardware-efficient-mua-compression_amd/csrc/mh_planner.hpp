@@ -81,6 +81,7 @@ struct WaveTask {
 struct PlanHost {
     mh_plan_info_t info{};
     uint32_t input_bits = 8;  // 8: one byte per sample; 4 / 2: packed pieces (mh_deinterleave_packed), whole-channel windows only
+    uint64_t chunk_stride = 0;  // packed input only: bytes between consecutive chunks of a channel (0 = contiguous)
     uint64_t max_T = 0;
     std::vector<uint64_t> ch_off, ch_len, w0, w1;
     std::vector<uint8_t> skip, sclv;
@@ -247,7 +248,9 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
             const uint32_t c = p.seg_ch[s];
             WaveTask t = record(c);
             const uint64_t first = p.w0[c] + p.seg_first[s];  // packed input: a multiple of 16 (whole-channel windows)
-            t.src_off = ch_off[c] + (p.input_bits == 8 ? first : (first >> 4) * (p.input_bits == 4 ? 8u : 4u));
+            t.src_off = ch_off[c] + (p.input_bits == 8 ? first
+                                     : p.chunk_stride ? (first / MH_CHUNK) * p.chunk_stride
+                                                      : (first >> 4) * (p.input_bits == 4 ? 8u : 4u));
             t.dst_off = p.seg_off[s];
             t.n = (uint32_t)p.seg_n[s];
             t.seg = s;

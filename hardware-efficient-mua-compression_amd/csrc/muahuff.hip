@@ -446,12 +446,12 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
                    uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
                    uint32_t K, uint32_t seg_chunks)
 {
-    return mh_plan_create_packed(plan, ch_off, ch_len, C, S, h, mode, window, sclv, K, seg_chunks, 8);
+    return mh_plan_create_packed(plan, ch_off, ch_len, C, S, h, mode, window, sclv, K, seg_chunks, 8, 0);
 }
 
 int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
                           uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
-                          uint32_t K, uint32_t seg_chunks, uint32_t input_bits)
+                          uint32_t K, uint32_t seg_chunks, uint32_t input_bits, uint64_t chunk_stride)
 {
     if (!plan || !ch_off || !ch_len || !sclv) return fail(MH_ERR_ARG, "mh_plan_create: NULL argument");
     *plan = nullptr;
@@ -460,6 +460,9 @@ int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t
     if (input_bits != 8 && window != MH_WIN_FULL)
         return fail(MH_ERR_ARG, "packed input needs the whole-channel window (MH_WIN_FULL)");
     if (input_bits == 2 && S > 4) return fail(MH_ERR_ARG, "2-bit input holds symbols 0..3: S=%u is above 4", S);
+    if (chunk_stride && (input_bits == 8 || chunk_stride % 16 || chunk_stride < (uint64_t)MH_CHUNK * input_bits / 8))
+        return fail(MH_ERR_ARG, "chunk_stride=%llu: packed input only, a multiple of 16, at least one chunk",
+                    (unsigned long long)chunk_stride);
     mh_plan_info_t I;
     if (int rc = plan_args(ch_len, C, S, h, mode, window, sclv, K, seg_chunks, &I)) return rc;
     int ndev = 0, dev = 0;
@@ -471,6 +474,7 @@ int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t
     p->device = dev;
     p->h.info = I;
     p->h.input_bits = input_bits;
+    p->h.chunk_stride = chunk_stride;
     mh::plan_host_build(p->h, ch_off, ch_len, sclv, plan_tuning());
     if (p->h.seg_ch.size() > 0xFFFFFFF0ull) {  // segment and task indices are 32-bit on the device
         mh_plan_destroy(p);
@@ -581,6 +585,7 @@ static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uin
     if (cal_mode == 0 && p->h.info.n_segments == 0) return MH_OK;
     mh::EncArgs a;
     a.cal_mode = cal_mode;
+    a.chunk_stride = p->h.chunk_stride;
     a.S = p->h.info.S;
     a.mode = p->h.info.mode;
     a.K = p->h.info.K;
@@ -886,6 +891,14 @@ int mh_rebin(const uint8_t *data, const uint64_t *in_off, const uint64_t *in_len
     return MH_OK;
 }
 
+static uint32_t layout_ablation()
+{
+#ifdef MH_TUNING
+    if (const char *e = getenv("MH_LAYOUT_ABL")) return (uint32_t)atoi(e);
+#endif
+    return 0;
+}
+
 int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, const uint64_t *out_off,
                     void *stream)
 {
@@ -893,32 +906,37 @@ int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, con
     if (T == 0) return MH_OK;
     const uint32_t tpw = 4;
     uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
-    if (bx > 0x7FFFFFFFull) bx = 0x7FFFFFFFull;
     const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
+    if (bx > 0x7FFFFFFFull / by) bx = 0x7FFFFFFFull / by;  // one grid dimension: strip fastest
     if (by > 65535) return fail(MH_ERR_ARG, "mh_deinterleave: C=%u too large", C);
-    hipLaunchKernelGGL(mh::k_deinterleave2<0>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
-                       out, out_off);
+    hipLaunchKernelGGL(mh::k_deinterleave2<0>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                       out, out_off, layout_ablation());
     MH_HIP(hipGetLastError());
     return MH_OK;
 }
 
 int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t bits, uint8_t *out,
-                           const uint64_t *out_off, void *stream)
+                           const uint64_t *out_off, uint64_t chunk_stride, void *stream)
 {
     if (!in || !out || !out_off || C == 0) return fail(MH_ERR_ARG, "mh_deinterleave_packed: bad argument");
     if (bits != 4 && bits != 2) return fail(MH_ERR_ARG, "mh_deinterleave_packed: bits=%u (4 or 2)", bits);
+    if (chunk_stride && (chunk_stride % 16 || chunk_stride < (uint64_t)MH_CHUNK * bits / 8))
+        return fail(MH_ERR_ARG, "mh_deinterleave_packed: chunk_stride=%llu", (unsigned long long)chunk_stride);
     if (T == 0) return MH_OK;
-    const uint32_t tpw = 4;
+    uint32_t tpw = 4;
+#ifdef MH_TUNING
+    if (const char *e = getenv("MH_LAYOUT_TPW")) tpw = (uint32_t)atoi(e);
+#endif
     uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
-    if (bx > 0x7FFFFFFFull) bx = 0x7FFFFFFFull;
     const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
+    if (bx > 0x7FFFFFFFull / by) bx = 0x7FFFFFFFull / by;  // one grid dimension: strip fastest
     if (by > 65535) return fail(MH_ERR_ARG, "mh_deinterleave_packed: C=%u too large", C);
     if (bits == 4)
-        hipLaunchKernelGGL(mh::k_deinterleave2<4>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
-                           out, out_off);
+        hipLaunchKernelGGL(mh::k_deinterleave2<4>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                           out, out_off, layout_ablation(), chunk_stride);
     else
-        hipLaunchKernelGGL(mh::k_deinterleave2<2>, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
-                           out, out_off);
+        hipLaunchKernelGGL(mh::k_deinterleave2<2>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                           out, out_off, layout_ablation(), chunk_stride);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }
@@ -929,10 +947,10 @@ int mh_interleave(const uint8_t *in, const uint64_t *in_off, uint64_t T, uint32_
     if (T == 0) return MH_OK;
     const uint32_t tpw = 4;
     uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
-    if (bx > 0x7FFFFFFFull) bx = 0x7FFFFFFFull;
     const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
+    if (bx > 0x7FFFFFFFull / by) bx = 0x7FFFFFFFull / by;  // one grid dimension: strip fastest
     if (by > 65535) return fail(MH_ERR_ARG, "mh_interleave: C=%u too large", C);
-    hipLaunchKernelGGL(mh::k_interleave, dim3((unsigned)bx, by), dim3(256), 0, (hipStream_t)stream, in, in_off, T, C,
+    hipLaunchKernelGGL(mh::k_interleave, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, in_off, T, C,
                        tpw, out);
     MH_HIP(hipGetLastError());
     return MH_OK;

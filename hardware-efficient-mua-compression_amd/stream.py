@@ -48,11 +48,14 @@ class StreamEncoder:
         slot = self._slots.get(Tb)
         if slot is None:
             bits = 2 if self.S <= 4 else 4
-            # packed layout: ceil(Tb / 16) pieces of 16 * bits / 8 bytes per channel
-            packed = ChannelSet.empty([(Tb + 15) // 16 * 2 * bits] * self.C, device=self.device)
-            cs = ChannelSet(packed.data, packed.ch_off, np.full(self.C, Tb, np.uint64))  # lengths in samples
+            # packed, chunk-blocked intermediate: chunk j (16384 samples = 1024 pieces) of channel c at
+            # (j * C + c) * chunk_bytes -- the chunks of one time range are neighbours
+            cb = 1024 * 2 * bits
+            nchunks = (Tb + 16383) // 16384
+            buf = torch.zeros(nchunks * self.C * cb + 16, dtype=torch.uint8, device=self.device)
+            cs = ChannelSet(buf, np.arange(self.C, dtype=np.uint64) * np.uint64(cb), np.full(self.C, Tb, np.uint64))
             plan = codec.Plan(cs.ch_off, cs.ch_len, self.S, 0, self.mode, WIN_FULL, self.sclv,
-                              seg_chunks=self.seg_chunks, input_bits=bits)
+                              seg_chunks=self.seg_chunks, input_bits=bits, chunk_stride=self.C * cb)
             e = plan.alloc_encoded()
             # the block's Encoded record points at the stored RAM word: nothing to copy per block
             e = codec.Encoded(e.payload, e.seg_words, e.ch_bits, self.peak, self.enc, e.skipped, e.seg_off, e.dense)
@@ -86,7 +89,7 @@ class StreamEncoder:
         cs, plan = slot["cs"], slot["plan"]
         _lib.check(_lib.lib().mh_deinterleave_packed(ct.c_void_p(t.data_ptr()), Tb, C, plan.input_bits,
                                                      ct.c_void_p(cs.data.data_ptr()),
-                                                     ct.c_void_p(slot["d_off"].data_ptr()),
+                                                     ct.c_void_p(slot["d_off"].data_ptr()), plan.chunk_stride,
                                                      ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
         enc = slot["enc"]
         _lib.check(_lib.lib().mh_encode_preset(plan._h, ct.c_void_p(cs.data.data_ptr()), ct.c_void_p(self.peak.data_ptr()),

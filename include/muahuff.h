@@ -113,10 +113,15 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
  * (bytes), as mh_deinterleave_packed writes them; input_bits = 8 is mh_plan_create.  Packed plans
  * cover whole channels (MH_WIN_FULL), 2-bit ones need S <= 4, and only mh_encode_preset reads
  * them (a calibrate-then-stream encoder has its (peak, encoder) word already); mh_decode on such a
- * plan writes ordinary bytes. */
+ * plan writes ordinary bytes.
+ * chunk_stride = 0: a channel's pieces are contiguous.  chunk_stride = B (a multiple of 16, at least
+ * one chunk = 1024 pieces): CHUNK-BLOCKED buffer -- the j-th 16384-sample chunk of channel i starts at
+ * ch_off[i] + j * B.  With ch_off[i] = i * chunk bytes and B = C * chunk bytes, all channels' chunks
+ * of one time range are neighbours: the de-interleaver then scatters each tile over one small region
+ * instead of C far-apart streams, which is what makes it fast. */
 int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_len, uint32_t C,
                           uint32_t S, uint32_t h, uint32_t mode, uint32_t window, const uint8_t *sclv,
-                          uint32_t K, uint32_t seg_chunks, uint32_t input_bits);
+                          uint32_t K, uint32_t seg_chunks, uint32_t input_bits, uint64_t chunk_stride);
 int mh_plan_destroy(mh_plan *plan);
 int mh_plan_info(const mh_plan *plan, mh_plan_info_t *info);
 /* host copies of the segment directory (each array n_segments long, any may be NULL):
@@ -223,11 +228,14 @@ int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, con
 /* The same transposition with the output clipped and packed: min(x, 15) in 4 bits per sample
  * (bits = 4) or min(x, 3) in 2 bits (bits = 2; enough when S <= 4).  The stream encoder clips at
  * S-1 anyway, so this halves / quarters the intermediate's trip through HBM.  Channel c is written
- * as ceil(T / 16) pieces of 8 / 4 bytes at out + out_off[c] (a cut last piece is zero-padded):
+ * as ceil(T / 16) pieces of 8 / 4 bytes at out + out_off[c] (a cut last piece is zero-padded;
+ * out_off[c] must be a multiple of 16 and the region behind it writable up to the next multiple of 16
+ * bytes past its last piece: the kernel stores 16 bytes at a time; chunk_stride as in
+ * mh_plan_create_packed: 0 = contiguous pieces, else chunk j of channel c starts at out_off[c] + j * chunk_stride):
  *   4 bits: dword0 byte j = s[j] | s[j+4] << 4, dword1 byte j = s[8+j] | s[12+j] << 4
  *   2 bits: dword  byte j = s[j] | s[j+4] << 2 | s[j+8] << 4 | s[j+12] << 6        (j = 0..3) */
 int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t bits, uint8_t *out,
-                           const uint64_t *out_off, void *stream);
+                           const uint64_t *out_off, uint64_t chunk_stride, void *stream);
 /* The inverse: channel c = T bytes at in + in_off[c]  ->  out[t*C + c] (what a decoder hands back
  * to a consumer of the implant-order stream).  in, in_off, out: device. */
 int mh_interleave(const uint8_t *in, const uint64_t *in_off, uint64_t T, uint32_t C, uint8_t *out,

@@ -525,6 +525,40 @@ def test_calibrate_then_stream_protocol(mh):
 
 
 @pytest.mark.parametrize("bits", [4, 2])
+def test_packed_deinterleave_chunk_blocked_layout(mh, bits):
+    """The same pieces in the chunk-blocked arrangement the stream encoder uses: chunk j of channel c at
+    out_off[c] + j * chunk_stride."""
+    import ctypes as ct
+    rng = np.random.RandomState(10 + bits)
+    lim, pb = (1 << bits) - 1, 2 * bits
+    cb = 1024 * pb
+    for T, C in ((16384 * 2 + 100, 5), (40000, 130), (16384, 3), (7, 2)):
+        x = rng.randint(0, 7, size=(T, C)).astype(np.uint8)
+        nchunks = (T + 16383) // 16384
+        stride = C * cb
+        out = torch.full((nchunks * stride + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        d_in = torch.from_numpy(x).cuda()
+        d_off = (torch.arange(C, dtype=torch.int64) * cb).cuda()
+        mh._lib.check(mh._lib.lib().mh_deinterleave_packed(ct.c_void_p(d_in.data_ptr()), T, C, bits, ct.c_void_p(out.data_ptr()),
+                                                           ct.c_void_p(d_off.data_ptr()), stride, None))
+        got = out.cpu().numpy()
+        npiece = (T + 15) // 16
+        s = np.zeros((C, npiece * 16), np.uint32)
+        s[:, :T] = np.minimum(x.T, lim)
+        s = s.reshape(C, npiece, 16)
+        if bits == 4:
+            by = np.concatenate([s[:, :, 0:4] | (s[:, :, 4:8] << 4), s[:, :, 8:12] | (s[:, :, 12:16] << 4)], axis=2)
+        else:
+            by = s[:, :, 0:4] | (s[:, :, 4:8] << 2) | (s[:, :, 8:12] << 4) | (s[:, :, 12:16] << 6)
+        by = by.astype(np.uint8)  # [C, npiece, pb]
+        for c in range(C):
+            for j in range(nchunks):
+                n = min(1024, npiece - j * 1024)
+                at = c * cb + j * stride
+                assert np.array_equal(got[at:at + n * pb], by[c, j * 1024:j * 1024 + n].reshape(-1)), (T, C, c, j)
+
+
+@pytest.mark.parametrize("bits", [4, 2])
 def test_packed_deinterleave_layout(mh, bits):
     """mh_deinterleave_packed against the layout include/muahuff.h documents, ragged T and C, counts
     far above the field's range (clipped, like the encoder clips at S-1)."""
@@ -541,7 +575,7 @@ def test_packed_deinterleave_layout(mh, bits):
         d_in = torch.from_numpy(x).cuda()
         d_off = torch.from_numpy(off).cuda()
         mh._lib.check(mh._lib.lib().mh_deinterleave_packed(ct.c_void_p(d_in.data_ptr()), T, C, bits, ct.c_void_p(out.data_ptr()),
-                                                           ct.c_void_p(d_off.data_ptr()), None))
+                                                           ct.c_void_p(d_off.data_ptr()), 0, None))
         got = out.cpu().numpy()
         s = np.zeros((C, npiece * 16), np.uint32)
         s[:, :T] = np.minimum(x.T, lim)
@@ -553,7 +587,8 @@ def test_packed_deinterleave_layout(mh, bits):
         want = by.astype(np.uint8).reshape(C, npiece * pb)
         for c in range(C):
             assert np.array_equal(got[off[c]:off[c] + npiece * pb], want[c]), (T, C, c)
-        assert (got[int(off[-1]) + npiece * pb:] == 0xEE).all()
+        end = (int(off[-1]) + npiece * pb + 15) // 16 * 16  # the kernel stores 16 bytes at a time (zeros behind the last piece)
+        assert (got[end:] == 0xEE).all()
 
 
 @pytest.mark.parametrize("S", [3, 4, 5, 10])

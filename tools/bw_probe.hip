@@ -137,6 +137,32 @@ __global__ __launch_bounds__(256) void k_wave_wr(const uint8_t* __restrict__ src
     }
 }
 
+// time-major strip read: the access pattern of k_deinterleave2.  A workgroup reads tiles of ROWS x W bytes
+// (W contiguous bytes of ROWS consecutive rows of a [T][C] matrix, 16 B per lane), tpw tiles along time;
+// strips fastest in the grid.  No LDS, no stores: the pattern's own ceiling.
+template <int W>
+__global__ __launch_bounds__(256) void k_strip_read(const uint8_t* __restrict__ in, size_t T, uint32_t C, uint32_t tpw, uint32_t* out)
+{
+    constexpr int ROWS = 32768 / W;                 // 32 KiB tiles
+    constexpr int LPR = W / 16;                     // lanes per row
+    const uint32_t nstrip = C / W;
+    const uint32_t c0 = (blockIdx.x % nstrip) * W;
+    const size_t ntiles = T / ROWS, gx = gridDim.x / nstrip;
+    u32x4 acc = {0,0,0,0};
+    for (size_t tile0 = (size_t)(blockIdx.x / nstrip) * tpw; tile0 < ntiles; tile0 += gx * tpw)
+        for (size_t tl = tile0; tl < tile0 + tpw && tl < ntiles; ++tl) {
+            u32x4 V[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t i = j * 256 + threadIdx.x, row = i / LPR, q = (i % LPR) * 16;
+                V[j] = __builtin_nontemporal_load((const u32x4*)(in + (tl * ROWS + row) * C + c0 + q));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc ^= V[j];
+        }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 template <typename F> float timeit(F f, int reps = 5)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -153,6 +179,14 @@ int main()
     CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes)); CK(hipMalloc(&out, 64));
     CK(hipMemset(src, 1, bytes)); CK(hipMemset(dst, 0, bytes));
     const size_t nvec = bytes / 16;
+    {
+        const uint32_t C = 1024; const size_t T = bytes / C;
+#define STRIP(W) { const uint32_t nstrip = C / W; const size_t ntiles = T / (32768 / W); const uint32_t tpw = 4; \
+            const size_t bx = (ntiles + tpw - 1) / tpw; \
+            float ms = timeit([&]{ hipLaunchKernelGGL(k_strip_read<W>, dim3((unsigned)(bx * nstrip)), dim3(256), 0, 0, src, T, C, tpw, out); }); \
+            printf("strip read W=%4d B x %3d rows per tile : %.3f ms  %.2f TB/s\n", W, 32768 / W, ms, bytes/ms/1e9); }
+        STRIP(128) STRIP(256) STRIP(512) STRIP(1024)
+    }
     for (uint32_t chunks : {4u, 8u, 16u, 38u}) {
         const size_t nseg = bytes / ((size_t)chunks * 16384);
         float ms = timeit([&]{ hipLaunchKernelGGL(k_wave_read<0>, dim3((nseg+3)/4), dim3(256), 0, 0, src, chunks, out, nseg); });
