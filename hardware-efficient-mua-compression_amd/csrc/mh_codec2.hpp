@@ -63,13 +63,8 @@ template <int PK>
 __device__ __forceinline__ uint32_t sample_at(const uint8_t *src, uint32_t idx)
 {
     if (PK == 0) return src[idx];
-    const uint32_t piece = idx >> 4, i = idx & 15u, j = i & 3u, g = i >> 2;
-    if (PK == 4) {
-        const uint32_t d = reinterpret_cast<const uint32_t *>(src)[piece * 2 + (g >> 1)];
-        return (d >> (8 * j + 4 * (g & 1u))) & 15u;
-    }
-    const uint32_t d = reinterpret_cast<const uint32_t *>(src)[piece];
-    return (d >> (8 * j + 2 * g)) & 3u;
+    if (PK == 4) return (src[idx >> 1] >> (4 * (idx & 1u))) & 15u;  // little-endian bit packing (mh_layout.hpp)
+    return (src[idx >> 2] >> (2 * (idx & 3u))) & 3u;
 }
 
 template <int PK>
@@ -179,17 +174,31 @@ __device__ __forceinline__ typename RawPiece<PK>::type load_row(const uint8_t *p
     }
 }
 
-// a loaded piece as four dwords of one byte per sample
+// ---- packed input: the 256-entry table is indexed by the stream's own bytes ---------------------
+// PK = 4: a byte is (b0 | b1 << 4), the PB = 4 pair index (xor-swizzled like the byte path's, for the banks).
+// PK = 2: a byte holds FOUR symbols; the table entry is their four codewords back to back (<= 12 bits for the
+//         S <= 4 this packing serves).  The hot entries -- all-zero byte, one non-zero symbol -- are 0 and the
+//         powers of two; folding index bits 5..7 into bits 0..3 puts them on distinct banks.
 template <int PK>
-__device__ __forceinline__ u32x4 expand_row(typename RawPiece<PK>::type r)
+__device__ __forceinline__ uint32_t packed_index_word(uint32_t w)
 {
-    if constexpr (PK == 0) {
-        return r;
-    } else if constexpr (PK == 4) {
-        return unpack_piece<4>(r.x, r.y);
-    } else {
-        return unpack_piece<2>(r, 0u);
+    if (PK == 4) return w ^ ((w >> 3) & 0x1F1F1F1Fu);
+    const uint32_t h = (w >> 5) & 0x07070707u;
+    return w ^ h ^ (h << 1);  // every byte: low bits ^= h ^ 2h, h < 8: stays inside the byte
+}
+
+// entry of the PK = 2 table for the byte `v`; sym(b) -> {code, length} of symbol b (0..3)
+template <class F>
+__device__ __forceinline__ uint2 quad_entry(uint32_t v, F sym)
+{
+    uint32_t code = 0, len = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint2 e = sym((v >> (2 * i)) & 3u);
+        code |= e.x << len;
+        len += e.y;
     }
+    return make_uint2(code, len);
 }
 
 // ---- per-wave LDS buffer of the encoder ------------------------------------------------------
@@ -361,6 +370,60 @@ __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t 
 #undef MH_FLUSH
 }
 
+// The same for a piece of packed input (r = 2 dwords of 4-bit or 1 dword of 2-bit samples): every byte of
+// the piece is a table index as it stands -- nothing is spread back to one byte per sample.  Used by the
+// full-chunk and the partial-chunk encoder alike.
+template <int LC, int PK, int ABL>
+__device__ __forceinline__ void encode_row_packed(typename RawPiece<PK>::type r, const uint2 *lut2, uint64_t &acc,
+                                                  uint32_t &nb, uint32_t &sp, uint32_t *st, uint32_t cap)
+{
+#define MH_FLUSH()                                               \
+    if (nb >= 32) {                                              \
+        if (ABL < 3 && sp < cap) st[sp * 16] = (uint32_t)acc;    \
+        acc >>= 32;                                              \
+        nb -= 32;                                                \
+        ++sp;                                                    \
+    }
+    if constexpr (PK == 2) {
+        // 16 codewords in four lookups; LC 0 (max length 2): they always fit one dword, LC 1 (<= 4): 8 do
+        const uint32_t y = packed_index_word<2>(r);
+        const uint2 e0 = lut2[y & 0xFFu], e1 = lut2[(y >> 8) & 0xFFu], e2 = lut2[(y >> 16) & 0xFFu], e3 = lut2[y >> 24];
+        const uint32_t t0 = e0.y + e1.y, t1 = e2.y + e3.y;
+        const uint32_t q0 = e0.x | (e1.x << e0.y), q1 = e2.x | (e3.x << e2.y);
+        if (LC == 0) {
+            acc |= (uint64_t)(q0 | (q1 << t0)) << nb;
+            nb += t0 + t1;
+            MH_FLUSH();
+        } else {
+            acc |= (uint64_t)q0 << nb; nb += t0; MH_FLUSH();
+            acc |= (uint64_t)q1 << nb; nb += t1; MH_FLUSH();
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {  // a dword = 8 samples = four pair lookups
+            const uint32_t y = packed_index_word<4>(o ? r.y : r.x);
+            const uint2 a0 = lut2[y & 0xFFu], a1 = lut2[(y >> 8) & 0xFFu];
+            const uint2 b0 = lut2[(y >> 16) & 0xFFu], b1 = lut2[y >> 24];
+            const uint32_t t0 = a0.y + a1.y, t1 = b0.y + b1.y;
+            if (LC == 3 && __builtin_expect(__any(t0 > 32u || t1 > 32u), 0)) {
+                acc |= (uint64_t)a0.x << nb; nb += a0.y; MH_FLUSH();
+                acc |= (uint64_t)a1.x << nb; nb += a1.y; MH_FLUSH();
+                acc |= (uint64_t)b0.x << nb; nb += b0.y; MH_FLUSH();
+                acc |= (uint64_t)b1.x << nb; nb += b1.y; MH_FLUSH();
+            } else if (LC >= 2 && __any(t0 + t1 > 32u)) {
+                acc |= (uint64_t)(a0.x | (a1.x << a0.y)) << nb; nb += t0; MH_FLUSH();
+                acc |= (uint64_t)(b0.x | (b1.x << b0.y)) << nb; nb += t1; MH_FLUSH();
+            } else {  // LC <= 1: 8 codewords of <= 4 bits always fit
+                const uint32_t q0 = a0.x | (a1.x << a0.y), q1 = b0.x | (b1.x << b0.y);
+                acc |= (uint64_t)(q0 | (q1 << t0)) << nb;
+                nb += t0 + t1;
+                if (LC != 0 || o == 1) { MH_FLUSH(); }
+            }
+        }
+    }
+#undef MH_FLUSH
+}
+
 // One full chunk.  v[] is a rolling window: row k of this chunk sits in v[k & 7]; after it is
 // consumed the slot is refilled with the row 8 KiB further on (this chunk, then the next one).
 // ABL (debug ablation, 0 in production): 1 no global stores, 2 also no merge, 3 also no staging
@@ -389,11 +452,17 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     }
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
-        u32x4 x = expand_row<PK>(v[k & (kWin - 1)]);
+        const typename RawPiece<PK>::type raw = v[k & (kWin - 1)];
         if (k < kRows - kWin)
             v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
         else if (HAS_NEXT)
             v[k & (kWin - 1)] = load_row<PK>(nxt + ((uint32_t)(k + kWin - kRows) * kLanes + lane) * piece_bytes<PK>());
+        if constexpr (PK != 0) {
+            encode_row_packed<LC, PK, ABL>(raw, lut2, acc, nb, sp, st, cap);
+            continue;
+        }
+        u32x4 x;
+        if constexpr (PK == 0) x = raw;
         if (ABL == 4) {
             acc += x.x ^ x.y ^ x.z ^ x.w;
             continue;
@@ -492,8 +561,12 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const uint32_t k = (uint32_t)(half * 8 + r);
-            if (k < nrows && k * kLanes + lane < nfp)  // the escapes inside ballot the active lanes only
-                encode_row<LC, PB, 0>(expand_row<PK>(v[r]), lut2, acc, nb, sp, st, cap);
+            if (k < nrows && k * kLanes + lane < nfp) {  // the escapes inside ballot the active lanes only
+                if constexpr (PK == 0)
+                    encode_row<LC, PB, 0>(v[r], lut2, acc, nb, sp, st, cap);
+                else
+                    encode_row_packed<LC, PK, 0>(v[r], lut2, acc, nb, sp, st, cap);
+            }
         }
     }
     const uint32_t cnt = m & 15u;
@@ -601,7 +674,9 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     {   // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
         const uint2 *g = a.e.lut + (size_t)ch * kLut;
         const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
-        if (threadIdx.x < (1u << (2 * PB))) {
+        if (PK == 2) {  // four-symbol table indexed by the packed byte
+            lut2[packed_index_word<2>(threadIdx.x) & 0xFFu] = quad_entry(threadIdx.x, [&](uint32_t b) { return g[b]; });
+        } else if (threadIdx.x < (1u << (2 * PB))) {
             const uint2 ea = g[b0], eb = g[b1];
             uint32_t idx = b0 | (b1 << PB);
             if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
@@ -671,7 +746,15 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
             if (a.e.skip_out) a.e.skip_out[t.ch] = (uint8_t)((t.flags >> 1) & 1u);
         }
     }
-    {
+    if (PK == 2) {
+#pragma unroll
+        for (uint32_t t0 = 0; t0 < 256; t0 += 64) {
+            const uint32_t tt = t0 + (uint32_t)lane;
+            lut2[packed_index_word<2>(tt) & 0xFFu] =
+                quad_entry(tt, [&](uint32_t b) { return make_uint2(__shfl(el.x, (int)b, 64), __shfl(el.y, (int)b, 64)); });
+        }
+        if (lane < kLut) lut1[lane] = el;
+    } else {
         constexpr uint32_t m = (1u << PB) - 1u;
 #pragma unroll
         for (uint32_t t0 = 0; t0 < (1u << (2 * PB)); t0 += 64) {

@@ -213,10 +213,11 @@ constexpr int kTr2T = 256, kTr2C = 128;
 // ---- packed pieces: the intermediate of the time-major (stream) path ----------------------------
 // A piece = 16 consecutive samples of one channel.  The stream encoder clips at S-1 <= 9 anyway, so
 // the de-interleaver may hand it min(x, 15) in 4 bits per sample -- or min(x, 3) in 2 bits when
-// S <= 4 -- and halve / quarter the intermediate's trip through HBM.  Layout, chosen so that the
-// encoder gets its four byte-per-sample dwords back with one shift and one mask each:
-//   4 bits:  dword0 byte j = s[j] | s[j+4] << 4,  dword1 byte j = s[8+j] | s[12+j] << 4
-//   2 bits:  dword  byte j = s[j] | s[j+4] << 2 | s[j+8] << 4 | s[j+12] << 6
+// S <= 4 -- and halve / quarter the intermediate's trip through HBM.  Layout: plain little-endian bit
+// packing, sample i of a channel's stream in bits [i * bits, (i + 1) * bits) -- so a byte of the 4-bit
+// stream IS the encoder's pair-table index (s[2j] | s[2j+1] << 4) and a byte of the 2-bit stream indexes a
+// four-symbol table directly; the encoder never spreads the samples back to bytes.  The de-interleaver
+// gets this order for free by choosing which time rows feed which dword of its byte transposition.
 __device__ __forceinline__ uint32_t clip_bytes(uint32_t d, uint32_t lim)
 {
     uint32_t r = 0;
@@ -229,6 +230,8 @@ __device__ __forceinline__ uint32_t clip_bytes(uint32_t d, uint32_t lim)
     return r;
 }
 
+// o = one byte per sample in TURNED order (see tr2_row): PK = 4: o.x / o.y = even / odd samples of the
+// piece's first 8, o.z / o.w of its last 8; PK = 2: o[f] byte j = sample 4j + f
 template <int PK>
 __device__ __forceinline__ void pack_piece(u32x4 o, uint32_t &p0, uint32_t &p1)
 {
@@ -249,24 +252,6 @@ __device__ __forceinline__ void pack_piece(u32x4 o, uint32_t &p0, uint32_t &p1)
     }
 }
 
-template <int PK>
-__device__ __forceinline__ u32x4 unpack_piece(uint32_t p0, uint32_t p1)
-{
-    u32x4 x;
-    if (PK == 4) {
-        x.x = p0 & 0x0F0F0F0Fu;
-        x.y = (p0 >> 4) & 0x0F0F0F0Fu;
-        x.z = p1 & 0x0F0F0F0Fu;
-        x.w = (p1 >> 4) & 0x0F0F0F0Fu;
-    } else {
-        x.x = p0 & 0x03030303u;
-        x.y = (p0 >> 2) & 0x03030303u;
-        x.z = (p0 >> 4) & 0x03030303u;
-        x.w = (p0 >> 6) & 0x03030303u;
-    }
-    return x;
-}
-
 // ragged-edge helpers of k_deinterleave2, kept out of line so the hot path's register
 // allocation is not shaped by them
 __device__ __noinline__ u32x4 tr2_load_partial(const uint8_t *src, uint32_t n)
@@ -284,6 +269,15 @@ __device__ __noinline__ void tr2_store_partial(uint8_t *dst, u32x4 o, uint32_t n
 }
 
 __device__ __forceinline__ uint32_t tr2_swz(uint32_t row) { return (((row >> 4) & 15u) << 1) ^ (row & 3u); }
+
+// time row (of a 16-step block) whose byte becomes byte j of dword m of a channel's turned piece: bytes in
+// time order for byte output; for the packed outputs the order that makes pack_piece's shifts-and-ors
+// produce plain little-endian bit packing
+template <int PK>
+__device__ __forceinline__ constexpr int tr2_row(int m, int j)
+{
+    return PK == 0 ? 4 * m + j : PK == 2 ? 4 * j + m : (m >> 1) * 8 + 2 * j + (m & 1);
+}
 
 // PK = 0: bytes out (channel c = T bytes at out + out_off[c]); PK = 4 / 2: packed pieces out
 // (channel c = ceil(T / 16) pieces of 8 / 4 bytes at out + out_off[c]; a cut last piece is zero-padded)
@@ -386,8 +380,9 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
                         d[i] = tile[(tbb * 16 + i) * (kTr2C / 4) + (cg ^ (tbb << 1) ^ (uint32_t)(i & 3))];
                     u32x4 o[4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {  // rows 4m..4m+3 -> dword m of each channel's 16 bytes
-                        const uint32_t a = d[4 * m], b = d[4 * m + 1], c = d[4 * m + 2], e = d[4 * m + 3];
+                    for (int m = 0; m < 4; ++m) {  // four rows -> dword m of each channel's 16 bytes
+                        const uint32_t a = d[tr2_row<PK>(m, 0)], b = d[tr2_row<PK>(m, 1)], c = d[tr2_row<PK>(m, 2)],
+                                       e = d[tr2_row<PK>(m, 3)];
                         const uint32_t t0_ = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
                         const uint32_t t1_ = __builtin_amdgcn_perm(e, c, 0x05010400u);  // c0 e0 c1 e1
                         const uint32_t t2_ = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
@@ -446,7 +441,10 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
                             // plain, not non-temporal: the workgroup's consecutive tiles extend the same lines of
                             // this channel, and the XCD's L2 merges them into whole lines before they go out --
                             // each visit of a channel's stream costs a DRAM row activation whatever it carries
-                            *reinterpret_cast<u32x4_u *>(dst) = pv;
+                            if (abl == 4)
+                                __builtin_nontemporal_store(pv, reinterpret_cast<u32x4_u *>(dst));
+                            else
+                                *reinterpret_cast<u32x4_u *>(dst) = pv;
                         }
                     }
                 }

@@ -244,20 +244,20 @@ template <int PK>
 static int dispatch_encode_packed(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t st)
 {
     const uint32_t L = p->h.info.maxlen;
-    const bool pb3 = p->h.info.S <= 8;
-    if (PK == 2) {  // S <= 4 only: maxlen <= 3, 3-bit pair packing
-        if (p->h.use_wave_tasks) return L <= 2 ? launch_encode2w<0, 3, 2>(a2, st) : launch_encode2w<1, 3, 2>(a2, st);
-        return L <= 2 ? launch_encode2<0, 3, 0, 2>(a2, st) : launch_encode2<1, 3, 0, 2>(a2, st);
+    if (PK == 2) {  // S <= 4 only: maxlen <= 3; the table is the four-symbol one (PB unused)
+        if (p->h.use_wave_tasks) return L <= 2 ? launch_encode2w<0, 4, 2>(a2, st) : launch_encode2w<1, 4, 2>(a2, st);
+        return L <= 2 ? launch_encode2<0, 4, 0, 2>(a2, st) : launch_encode2<1, 4, 0, 2>(a2, st);
     }
+    // 4-bit pieces: a byte of the stream is the PB = 4 pair index
     if (p->h.use_wave_tasks) {
-        if (L <= 2) return pb3 ? launch_encode2w<0, 3, 4>(a2, st) : launch_encode2w<0, 4, 4>(a2, st);
-        if (L <= 4) return pb3 ? launch_encode2w<1, 3, 4>(a2, st) : launch_encode2w<1, 4, 4>(a2, st);
-        if (L <= 8) return pb3 ? launch_encode2w<2, 3, 4>(a2, st) : launch_encode2w<2, 4, 4>(a2, st);
+        if (L <= 2) return launch_encode2w<0, 4, 4>(a2, st);
+        if (L <= 4) return launch_encode2w<1, 4, 4>(a2, st);
+        if (L <= 8) return launch_encode2w<2, 4, 4>(a2, st);
         return launch_encode2w<3, 4, 4>(a2, st);
     }
-    if (L <= 2) return pb3 ? launch_encode2<0, 3, 0, 4>(a2, st) : launch_encode2<0, 4, 0, 4>(a2, st);
-    if (L <= 4) return pb3 ? launch_encode2<1, 3, 0, 4>(a2, st) : launch_encode2<1, 4, 0, 4>(a2, st);
-    if (L <= 8) return pb3 ? launch_encode2<2, 3, 0, 4>(a2, st) : launch_encode2<2, 4, 0, 4>(a2, st);
+    if (L <= 2) return launch_encode2<0, 4, 0, 4>(a2, st);
+    if (L <= 4) return launch_encode2<1, 4, 0, 4>(a2, st);
+    if (L <= 8) return launch_encode2<2, 4, 0, 4>(a2, st);
     return launch_encode2<3, 4, 0, 4>(a2, st);
 }
 

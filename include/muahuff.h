@@ -232,8 +232,9 @@ int mh_deinterleave(const uint8_t *in, uint64_t T, uint32_t C, uint8_t *out, con
  * out_off[c] must be a multiple of 16 and the region behind it writable up to the next multiple of 16
  * bytes past its last piece: the kernel stores 16 bytes at a time; chunk_stride as in
  * mh_plan_create_packed: 0 = contiguous pieces, else chunk j of channel c starts at out_off[c] + j * chunk_stride):
- *   4 bits: dword0 byte j = s[j] | s[j+4] << 4, dword1 byte j = s[8+j] | s[12+j] << 4
- *   2 bits: dword  byte j = s[j] | s[j+4] << 2 | s[j+8] << 4 | s[j+12] << 6        (j = 0..3) */
+ * plain little-endian bit packing -- sample i of the channel in bits [i * bits, (i + 1) * bits) of its stream:
+ *   4 bits: byte j = s[2j] | s[2j+1] << 4
+ *   2 bits: byte j = s[4j] | s[4j+1] << 2 | s[4j+2] << 4 | s[4j+3] << 6 */
 int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t bits, uint8_t *out,
                            const uint64_t *out_off, uint64_t chunk_stride, void *stream);
 /* The inverse: channel c = T bytes at in + in_off[c]  ->  out[t*C + c] (what a decoder hands back

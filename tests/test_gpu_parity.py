@@ -524,6 +524,17 @@ def test_calibrate_then_stream_protocol(mh):
             assert int(c.ch_bits[ch]) == int(lens.sum()), ch
 
 
+def _bitpack(s, bits):
+    """little-endian bit packing of the last axis (16 samples -> 2 * bits bytes): sample i in bits
+    [i * bits, (i + 1) * bits) -- the layout include/muahuff.h documents for mh_deinterleave_packed"""
+    per = 8 // bits
+    g = s.reshape(s.shape[:-1] + (16 // per, per)).astype(np.uint32)
+    by = np.zeros(g.shape[:-1], np.uint32)
+    for f in range(per):
+        by |= g[..., f] << (bits * f)
+    return by.astype(np.uint8)
+
+
 @pytest.mark.parametrize("bits", [4, 2])
 def test_packed_deinterleave_chunk_blocked_layout(mh, bits):
     """The same pieces in the chunk-blocked arrangement the stream encoder uses: chunk j of channel c at
@@ -546,11 +557,7 @@ def test_packed_deinterleave_chunk_blocked_layout(mh, bits):
         s = np.zeros((C, npiece * 16), np.uint32)
         s[:, :T] = np.minimum(x.T, lim)
         s = s.reshape(C, npiece, 16)
-        if bits == 4:
-            by = np.concatenate([s[:, :, 0:4] | (s[:, :, 4:8] << 4), s[:, :, 8:12] | (s[:, :, 12:16] << 4)], axis=2)
-        else:
-            by = s[:, :, 0:4] | (s[:, :, 4:8] << 2) | (s[:, :, 8:12] << 4) | (s[:, :, 12:16] << 6)
-        by = by.astype(np.uint8)  # [C, npiece, pb]
+        by = _bitpack(s, bits)  # [C, npiece, pb]
         for c in range(C):
             for j in range(nchunks):
                 n = min(1024, npiece - j * 1024)
@@ -580,11 +587,7 @@ def test_packed_deinterleave_layout(mh, bits):
         s = np.zeros((C, npiece * 16), np.uint32)
         s[:, :T] = np.minimum(x.T, lim)
         s = s.reshape(C, npiece, 16)
-        if bits == 4:  # dword0 byte j = s[j] | s[j+4] << 4, dword1 byte j = s[8+j] | s[12+j] << 4
-            by = np.concatenate([s[:, :, 0:4] | (s[:, :, 4:8] << 4), s[:, :, 8:12] | (s[:, :, 12:16] << 4)], axis=2)
-        else:          # byte j = s[j] | s[j+4] << 2 | s[j+8] << 4 | s[j+12] << 6
-            by = s[:, :, 0:4] | (s[:, :, 4:8] << 2) | (s[:, :, 8:12] << 4) | (s[:, :, 12:16] << 6)
-        want = by.astype(np.uint8).reshape(C, npiece * pb)
+        want = _bitpack(s, bits).reshape(C, npiece * pb)
         for c in range(C):
             assert np.array_equal(got[off[c]:off[c] + npiece * pb], want[c]), (T, C, c)
         end = (int(off[-1]) + npiece * pb + 15) // 16 * 16  # the kernel stores 16 bytes at a time (zeros behind the last piece)

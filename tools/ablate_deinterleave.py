@@ -17,17 +17,17 @@ lib = muahuff._lib.lib()
 vp = ct.c_void_p
 C, T = 1024, int(os.environ.get("T", "10000000"))
 x = torch.randint(0, 4, (T, C), dtype=torch.uint8, device="cuda")
-out = torch.zeros(T * C + 4096, dtype=torch.uint8, device="cuda")
+out = torch.zeros(T * C + (1 << 24), dtype=torch.uint8, device="cuda")
 for bits in (8, 4, 2):
     stride = (T + 15) // 16 * 2 * bits if bits != 8 else T
     stride = (stride + 15) // 16 * 16
     off = torch.arange(C, dtype=torch.int64, device="cuda") * stride
-    for tpw, blocked in (((4, 0),) if bits == 8 else ((4, 0), (4, 1), (16, 1))):
+    for tpw, blocked, pad in (((4, 0, 0),) if bits == 8 else ((4, 0, 0), (4, 1, 0), (2, 1, 0), (4, 1, 64), (4, 1, 128), (4, 1, 256), (4, 1, 1024))):
         os.environ["MH_LAYOUT_TPW"] = str(tpw)
-        cb = 1024 * 2 * bits                      # bytes of one 16384-sample chunk
+        cb = 1024 * 2 * bits + pad                # bytes of one 16384-sample chunk (+ skew between channels)
         if blocked:                               # chunk-blocked: channel c at c * cb, chunk j at + j * C * cb
             off = torch.arange(C, dtype=torch.int64, device="cuda") * cb
-        for abl in (0, 1):
+        for abl in ((0, 1) if bits == 8 else (0, 4, 1)):
             os.environ["MH_LAYOUT_ABL"] = str(abl)
 
             def run():
@@ -44,4 +44,4 @@ for bits in (8, 4, 2):
                 run()
             b.record()
             torch.cuda.synchronize()
-            print("out bits %d  tpw %2d  %s  ablation %d : %.3f ms" % (bits, tpw, "blocked" if blocked else "linear ", abl, a.elapsed_time(b) / 5), flush=True)
+            print("out bits %d  tpw %2d  %s pad %4d  ablation %d : %.3f ms" % (bits, tpw, "blocked" if blocked else "linear ", pad, abl, a.elapsed_time(b) / 5), flush=True)
