@@ -132,6 +132,8 @@ __device__ __noinline__ uint2 encode_chunk_slow(const uint8_t *__restrict__ src,
 //     always fit 32 bits); 2 maxlen<=8: one per 2 dwords when 8 codewords fit 32 bits in every lane
 //     of the wave, else one per dword; 3 maxlen==9: as 2, plus a per-pair route when four codewords
 //     exceed a dword.  The escapes are wave-uniform branches on __any().
+//     For LC <= 1 the staging (8 * maxlen dwords per lane, enc_stage_dw) holds the worst case of a chunk,
+//     so the staging-full checks and the overflow route compile away.
 // PB: bits per symbol in the pair index.  PB=3 (S<=8) keeps the hot entries (small symbols) on
 //     distinct LDS banks; PB=4 (S=9,10) xor-swizzles the index for the same reason.
 constexpr int kWin = 8;  // rows (1 KiB each) a wave keeps in flight
@@ -158,6 +160,50 @@ __device__ __forceinline__ uint32_t clip_word(uint32_t d)
     }
     return r;
 }
+
+// The two pair-table entries of a dword of four clipped symbols.  The index is formed pre-scaled by the
+// entry size: for PB = 3, (x << 3 | x >> 2) has (b0 | b1 << 3) * 8 in bits 3..8 and (b2 | b3 << 3) * 8 in bits
+// 19..24 -- two masks away from the two LDS byte offsets (4 VALU per dword instead of 6).
+template <int PB>
+__device__ __forceinline__ void pair_entries(uint32_t x, const uint2 *lut2, uint2 &e0, uint2 &e1)
+{
+    const char *base = reinterpret_cast<const char *>(lut2);
+    if (PB == 3) {
+        uint32_t y8;  // (x << 3) | (x >> 2) in two instructions (the compiler spends three and a fused and-or)
+        asm("v_lshl_or_b32 %0, %1, 3, %2" : "=v"(y8) : "v"(x), "v"(x >> 2));
+        e0 = *reinterpret_cast<const uint2 *>(base + (y8 & 0x1F8u));
+        e1 = *reinterpret_cast<const uint2 *>(base + ((y8 >> 16) & 0x1F8u));
+    } else {
+        const uint32_t y8 = pair_index_word<PB>(x) << 3;
+        e0 = *reinterpret_cast<const uint2 *>(base + (y8 & 0x7F8u));
+        e1 = *reinterpret_cast<const uint2 *>(base + ((y8 >> 16) & 0x7F8u));
+    }
+}
+
+// Short codes (LC 0: max length 2, LC 1: max length 4): the 16 codewords of a piece.  Everything that fits
+// 32 bits is put together in 32-bit arithmetic first -- LC 0: the whole piece (<= 32 bits), LC 1: each half --
+// so the lane's 64-bit accumulator is touched once resp. twice per piece.
+#define MH_SHORT_CODES_ROW(x)                                                          \
+    {                                                                                  \
+        uint2 e0, e1, e2, e3, e4, e5, e6, e7;                                          \
+        pair_entries<PB>((x).x, lut2, e0, e1);                                         \
+        pair_entries<PB>((x).y, lut2, e2, e3);                                         \
+        pair_entries<PB>((x).z, lut2, e4, e5);                                         \
+        pair_entries<PB>((x).w, lut2, e6, e7);                                         \
+        const uint32_t q0 = e0.x | (e1.x << e0.y), t0 = e0.y + e1.y;                   \
+        const uint32_t q1 = e2.x | (e3.x << e2.y), t1 = e2.y + e3.y;                   \
+        const uint32_t q2 = e4.x | (e5.x << e4.y), t2 = e4.y + e5.y;                   \
+        const uint32_t q3 = e6.x | (e7.x << e6.y), t3 = e6.y + e7.y;                   \
+        const uint32_t h0 = q0 | (q1 << t0), h1 = q2 | (q3 << t2);                     \
+        if (LC == 0) {                                                                 \
+            acc |= (uint64_t)(h0 | (h1 << (t0 + t1))) << nb;                           \
+            nb += t0 + t1 + t2 + t3;                                                   \
+            MH_FLUSH();                                                                \
+        } else {                                                                       \
+            acc |= (uint64_t)h0 << nb; nb += t0 + t1; MH_FLUSH();                      \
+            acc |= (uint64_t)h1 << nb; nb += t2 + t3; MH_FLUSH();                      \
+        }                                                                              \
+    }
 
 template <int PK>
 __device__ __forceinline__ typename RawPiece<PK>::type load_row(const uint8_t *p)
@@ -319,7 +365,7 @@ __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t 
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
 #define MH_FLUSH()                                               \
     if (nb >= 32) {                                              \
-        if (ABL < 3 && sp < cap) st[sp * 16] = (uint32_t)acc;    \
+        if (ABL < 3 && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
         acc >>= 32;                                              \
         nb -= 32;                                                \
         ++sp;                                                    \
@@ -356,16 +402,7 @@ __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t 
             }
         }
     } else {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const uint32_t y = pair_index_word<PB>(x[d]);
-            const uint2 e0 = lut2[y & 0xFFu];
-            const uint2 e1 = lut2[(y >> 16) & 0xFFu];
-            const uint32_t q = e0.x | (e1.x << e0.y);
-            acc |= (uint64_t)q << nb;
-            nb += e0.y + e1.y;
-            if ((LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
-        }
+        MH_SHORT_CODES_ROW(x)
     }
 #undef MH_FLUSH
 }
@@ -379,7 +416,7 @@ __device__ __forceinline__ void encode_row_packed(typename RawPiece<PK>::type r,
 {
 #define MH_FLUSH()                                               \
     if (nb >= 32) {                                              \
-        if (ABL < 3 && sp < cap) st[sp * 16] = (uint32_t)acc;    \
+        if (ABL < 3 && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
         acc >>= 32;                                              \
         nb -= 32;                                                \
         ++sp;                                                    \
@@ -445,7 +482,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
 #define MH_FLUSH()                                               \
     if (nb >= 32) {                                              \
-        if (ABL < 3 && sp < cap) st[sp * 16] = (uint32_t)acc;    \
+        if (ABL < 3 && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
         acc >>= 32;                                              \
         nb -= 32;                                                \
         ++sp;                                                    \
@@ -499,16 +536,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
                 }
             }
         } else {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t y = pair_index_word<PB>(x[d]);
-                const uint2 e0 = lut2[y & 0xFFu];
-                const uint2 e1 = lut2[(y >> 16) & 0xFFu];
-                const uint32_t q = e0.x | (e1.x << e0.y);
-                acc |= (uint64_t)q << nb;
-                nb += e0.y + e1.y;
-                if ((LC == 1 && (d & 1)) || (LC == 0 && d == 3)) { MH_FLUSH(); }
-            }
+            MH_SHORT_CODES_ROW(x)
         }
     }
 #undef MH_FLUSH
@@ -519,11 +547,11 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     }
     const uint32_t tot = sp * 32 + nb;
     if (nb > 0) {
-        if (sp < cap) st[sp * 16] = (uint32_t)acc;
+        if (LC <= 1 || sp < cap) st[sp * 16] = (uint32_t)acc;
         ++sp;
     }
     MH_WAVE_SYNC();
-    if (__any(sp > cap)) {
+    if (LC >= 2 && __any(sp > cap)) {
         overflow_chunk<false, PK>(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
         return;
     }
@@ -578,7 +606,7 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
             acc |= (uint64_t)e.x << nb;
             nb += e.y;
             if (nb >= 32) {
-                if (sp < cap) st[sp * 16] = (uint32_t)acc;
+                if (LC <= 1 || sp < cap) st[sp * 16] = (uint32_t)acc;
                 acc >>= 32;
                 nb -= 32;
                 ++sp;
@@ -587,11 +615,11 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
     }
     const uint32_t tot = sp * 32 + nb;
     if (nb > 0) {
-        if (sp < cap) st[sp * 16] = (uint32_t)acc;
+        if (LC <= 1 || sp < cap) st[sp * 16] = (uint32_t)acc;
         ++sp;
     }
     MH_WAVE_SYNC();
-    if (__any(sp > cap))
+    if (LC >= 2 && __any(sp > cap))
         overflow_chunk<true, PK>(src, m, lut1, buf, dst, pend, lane, words, bits);
     else
         merge_and_flush<NE, 0>(buf, cap, tot, sp, dst, pend, lane, words, bits);
@@ -663,14 +691,17 @@ __device__ __forceinline__ uint64_t stream_bytes(uint64_t t) { return PK == 0 ? 
 template <int LC, int PB, int ABL = 0, int PK = 0>
 __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // the workgroup's tables are STATIC shared memory: their addresses are compile-time constants that go into
+    // the offset field of the ds_read, so a pre-scaled table index is the instruction's address operand as it is
+    __shared__ __attribute__((aligned(16))) uint2 s_tab[kEncSharedDw / 2];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // the four waves' staging buffers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t task = blockIdx.x;
     const uint32_t seg0 = a.t.task_seg0[task];
     const uint32_t nseg = a.t.task_n[task];
     const uint32_t ch = a.e.seg_ch[seg0];
-    uint2 *lut2 = reinterpret_cast<uint2 *>(smem);
-    uint2 *lut1 = reinterpret_cast<uint2 *>(smem + 512);
+    uint2 *lut2 = s_tab;
+    uint2 *lut1 = s_tab + 256;
     {   // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
         const uint2 *g = a.e.lut + (size_t)ch * kLut;
         const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
@@ -687,7 +718,7 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     __syncthreads();
     if ((uint32_t)wave >= nseg) return;
     const uint32_t cap = a.e.stage_dw;
-    uint32_t *buf = smem + kEncSharedDw + (size_t)wave * enc2_wave_dwords(cap);
+    uint32_t *buf = smem + (size_t)wave * enc2_wave_dwords(cap);
     const uint32_t seg = seg0 + (uint32_t)wave;
     typename RawPiece<PK>::type v[kWin];
     uint64_t bits;

@@ -197,7 +197,7 @@ static int prepare_kernel(const void *kern, size_t lds, bool needs_lds_base_0)
 template <int LC, int PB, int ABL = 0, int PK = 0>
 static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 {
-    const size_t lds = ((size_t)mh::kEncSharedDw + 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw)) * sizeof(uint32_t);
+    const size_t lds = 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw) * sizeof(uint32_t);  // + the static tables
     auto kern = mh::k_encode2<LC, PB, ABL, PK>;
     if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
     hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Same-box A/B of two builds of libmuahuff.so: encode / decode of the roofline set (1024 channels x
+1e7 bins) per S and of the short-channel set, each library in its own child process, alternating.
+usage: ab_libs.py A.so B.so ...      (children: ab_libs.py --one X.so)"""
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def one(path):
+    import numpy as np
+    import torch
+
+    import muahuff
+    muahuff._lib.use_library(path)
+    from muahuff import codec, sclv, synth
+
+    def timed(f, n):
+        for _ in range(3):
+            f()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record()
+            f()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
+
+    Ss = [int(v) for v in os.environ.get("SS", "3,5,8,10").split(",")]
+    for C, T, n in ((1024, 10_000_000, 30), (2400, 72_000, 50)):
+        cs = synth.generate(C, T, seed=5)
+        out = torch.empty_like(cs.data)
+        for S in (Ss if T > 1_000_000 else Ss[:1]):
+            plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(S))
+            enc = plan.alloc_encoded()
+            e = timed(lambda: plan.encode(cs.data, out=enc), n)
+            d = timed(lambda: plan.decode(enc, out), n)
+            b = float(enc.ch_bits.sum()) / plan.window_samples
+            ab = plan.window_samples * (1 + b / 8)
+            print("%-28s %5d x %8d S=%2d : encode %8.1f us (%.3f)  decode %8.1f us (%.3f)"
+                  % (os.path.basename(path), C, T, S, e, ab / e / 8e6, d, ab / d / 8e6), flush=True)
+            plan.close()
+            del enc
+        del cs, out
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--one":
+        one(os.path.abspath(sys.argv[2]))
+    else:
+        for rep in range(int(os.environ.get("REPS", "2"))):
+            for p in sys.argv[1:]:
+                rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--one", p])
+                if rc:
+                    sys.exit(rc)
