@@ -752,24 +752,55 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
     const uint8_t *src = a.e.data + t.src_off;  // the planner's records hold byte offsets of the plan's input packing
     typename RawPiece<PK>::type v[kWin];
     uint2 el = make_uint2(0u, 0u);  // the 16 single-symbol entries {bit-reversed code, length}, one per lane
+    // The segment's first rows are requested before the tables are built -- but AFTER the few small loads the
+    // tables depend on: the memory counter retires in order, so those are waited for with the rows still in
+    // flight.  The row loads are unconditional for the same reason (loads inside a branch cannot be counted,
+    // and every wait after them would drain the queue); a record shorter than a chunk, which will not use
+    // them, re-reads one piece it may read anyway.
+    const bool full = t.n >= (uint32_t)kChunk;
+    const uint8_t *first = t.n ? src : a.e.data + (t.cal_off & ~(uint64_t)15);
+    const int frow = full ? 1 : 0;
+    auto first_rows = [&]() {
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            v[k] = load_row<PK>(first + (size_t)frow * (((uint32_t)k * kLanes + lane) * piece_bytes<PK>()));
+            asm volatile("" ::: "memory");  // keep the rows in issue order
+        }
+    };
     if (a.e.cal_mode == 0) {
         if (lane < kLut) el = a.e.lut[(size_t)t.ch * kLut + lane];
-        if (t.n >= (uint32_t)kChunk) load_first_rows<PK>(v, src, lane);  // in flight during the table build
+        first_rows();
     } else {
-        if (t.n >= (uint32_t)kChunk) load_first_rows<PK>(v, src, lane);
         const int S = (int)a.e.S;
+        const uint32_t K = a.e.K;
+        // <= 4 encoders: the whole code table is one dword per lane, fetched before anything is known
+        const bool codes_in_regs = K * 16u <= 64u;
+        const uint32_t pre = a.e.codes[(uint32_t)lane < K * 16u ? (uint32_t)lane : 0u];  // (unconditional: see first_rows)
+        // calibrating (mode 1) and preset (mode 2) records issue the SAME loads -- a branch between two sets of
+        // loads makes the compiler wait at the join -- from addresses that are valid in either mode; the mode
+        // decides afterwards which results are used
+        const bool preset = a.e.cal_mode != 1;
+        const uint8_t *cal = a.e.data + (preset ? (t.src_off & ~(uint64_t)15) : t.cal_off);
+        const uint32_t cal_n = preset ? 1u : t.cal_n;
+        const uint8_t *pk = preset ? a.e.peak_in + t.ch : cal, *en = preset ? a.e.enc_in + t.ch : cal;
+        const CalLoads cl = wave_calibrate_issue(cal, cal_n, S, K, a.e.sclv, lane);
+        const int pi = *pk;
+        const uint32_t ki = *en;
+        first_rows();
         int p;
         uint32_t k;
-        if (a.e.cal_mode == 1) {
-            wave_calibrate(a.e.data + t.cal_off, t.cal_n, S, a.e.mode, a.e.K, a.e.sclv, lane, p, k);
+        if (!preset) {
+            wave_calibrate_finish(cl, cal, cal_n, S, a.e.mode, K, a.e.sclv, lane, p, k);
         } else {  // preset word; out-of-range values decode as 0 like k_lut_preset
-            p = a.e.peak_in[t.ch] < S ? a.e.peak_in[t.ch] : 0;
-            k = a.e.enc_in[t.ch] < a.e.K ? a.e.enc_in[t.ch] : 0;
+            p = pi < S ? pi : 0;
+            k = ki < K ? ki : 0;
         }
-        if (lane < kLut) {
+        {
             const int sym = lane > S - 1 ? S - 1 : lane;
-            const uint32_t e = a.e.codes[k * 16 + rank_of_symbol((int)a.e.mode, S, p, sym)];
-            el = make_uint2(e & 0xFFFFu, e >> 16);
+            const uint32_t at = k * 16 + (uint32_t)rank_of_symbol((int)a.e.mode, S, p, sym & 15);
+            uint32_t e = __shfl(pre, (int)(at & 63u), 64);
+            if (!codes_in_regs && lane < kLut) e = a.e.codes[at];
+            if (lane < kLut) el = make_uint2(e & 0xFFFFu, e >> 16);
         }
         if ((t.flags & 1u) && lane == 0) {  // the channel's first record publishes its word
             if (a.e.peak_out) a.e.peak_out[t.ch] = (uint8_t)p;
@@ -1317,11 +1348,17 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (kEntDw << W));
     const uint64_t pos = a.plan_slots ? t.dst_off : a.d.seg_off[t.seg];
     // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
-    const int p = a.peak[t.ch] < S ? a.peak[t.ch] : 0;
-    const uint32_t k = a.enc[t.ch] < a.nK ? a.enc[t.ch] : 0;
+    // (<= 4 encoders: the whole code table is one dword per lane, requested together with the channel's word
+    // instead of after it -- one memory round trip before the tables instead of two)
+    const uint32_t pre = a.codes[(uint32_t)lane < a.nK * 16u ? (uint32_t)lane : 0u];
+    const int pi = a.peak[t.ch];
+    const uint32_t ki = a.enc[t.ch];
+    const int p = pi < S ? pi : 0;
+    const uint32_t k = ki < a.nK ? ki : 0;
     // rank r of the channel's code: bit-reversed code | len << 16 | symbol << 24, one rank per lane
-    uint32_t mine = 0;
-    if (lane < S) mine = a.codes[k * 16 + lane] | ((uint32_t)symbol_of_rank((int)a.mode, S, p, lane) << 24);
+    uint32_t code = __shfl(pre, (int)((k * 16 + (uint32_t)lane) & 63u), 64);
+    if (a.nK * 16u > 64u && lane < S) code = a.codes[k * 16 + lane];
+    const uint32_t mine = lane < S ? code | ((uint32_t)symbol_of_rank((int)a.mode, S, p, lane) << 24) : 0u;
     uint32_t rk[MH_LUT_SYMS];
 #pragma unroll
     for (int r = 0; r < MH_LUT_SYMS; ++r) rk[r] = __shfl(mine, r, 64);

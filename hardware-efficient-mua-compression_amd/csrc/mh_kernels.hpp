@@ -309,20 +309,45 @@ struct EncArgs {
 // histogram of min(x, S-1) over x[0, c), first-max peak, approx-sort ranks, first-min encoder over
 // the K rows -- lane k prices encoder k, so K = 35 costs as much as K = 1.
 // Compressing data/get_BR_with_approx_sort.py:164-176, 254, 281; functions_1.py:75-90.
-__device__ __forceinline__ void wave_calibrate(const uint8_t *x, uint32_t c, int S, uint32_t mode, uint32_t K,
-                                               const uint8_t *sclv, int lane, int &p_out, uint32_t &k_out)
+// Split in two so that the caller can put its own (long) loads between the halves: the vector-memory counter
+// retires in order, so what the calibration needs is requested FIRST and waited for with the rest in flight.
+struct CalLoads {
+    int v0;                       // sample `lane` of the window (-1 past its end)
+    uint32_t len[MH_LUT_SYMS];    // code lengths of encoder `lane` by rank (lanes >= K: unused)
+};
+
+__device__ __forceinline__ CalLoads wave_calibrate_issue(const uint8_t *x, uint32_t c, int S, uint32_t K,
+                                                         const uint8_t *sclv, int lane)
 {
+    // unconditional loads from clamped (always valid) addresses; what does not apply is masked in the second
+    // half -- a load inside a branch would be waited for on the spot
+    CalLoads l;
+    const uint32_t i = (uint32_t)lane < c ? (uint32_t)lane : (c ? c - 1 : 0u);
+    l.v0 = (int)x[i];
+    const uint32_t row = ((uint32_t)lane < K ? (uint32_t)lane : K - 1) * (uint32_t)S;
+#pragma unroll
+    for (int r = 0; r < MH_LUT_SYMS; ++r) l.len[r] = sclv[row + (uint32_t)(r < S ? r : S - 1)];
+    return l;
+}
+
+__device__ __forceinline__ void wave_calibrate_finish(const CalLoads &l, const uint8_t *x, uint32_t c, int S,
+                                                      uint32_t mode, uint32_t K, const uint8_t *sclv, int lane,
+                                                      int &p_out, uint32_t &k_out)
+{
+    // wave-uniform counts from ballots: they live in scalar registers, and so does everything derived from
+    // them up to the pricing -- a record of a short channel spends ~150 instructions here, not ~700
     uint32_t cnt[MH_LUT_SYMS];
 #pragma unroll
     for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = 0;
-    for (uint32_t i = lane; i < c; i += 64) {
-        int v = x[i];
+    for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        int v = i0 == 0 ? l.v0 : (int)x[i < c ? i : c - 1];
+        v = i < c ? v : -1;  // -1 matches no symbol
         v = v > S - 1 ? S - 1 : v;
 #pragma unroll
-        for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] += (v == s);
+        for (int s = 0; s < MH_LUT_SYMS; ++s)
+            if (s < S) cnt[s] += (uint32_t)__popcll(__ballot(v == s));
     }
-#pragma unroll
-    for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = s < S ? wave_sum_u32(cnt[s]) : 0u;
     int p = 0;
     if (mode == MH_MODE_APPROX) {
         uint32_t best = cnt[0];
@@ -344,7 +369,13 @@ __device__ __forceinline__ void wave_calibrate(const uint8_t *x, uint32_t c, int
     }
     // cost <= 9 * 4096 < 2^24 and k < 256: (cost << 8 | k) orders by cost, then by encoder index
     uint32_t key = 0xFFFFFFFFu;
-    for (uint32_t k = lane; k < K; k += 64) {
+    if ((uint32_t)lane < K) {
+        uint32_t cost = 0;
+#pragma unroll
+        for (int r = 0; r < MH_LUT_SYMS; ++r) cost += l.len[r] * sorted[r];  // sorted[] is 0 beyond S
+        key = (cost << 8) | (uint32_t)lane;
+    }
+    for (uint32_t k = 64 + lane; k < K; k += 64) {  // more than 64 encoders: the rest from memory
         uint32_t cost = 0;
 #pragma unroll
         for (int r = 0; r < MH_LUT_SYMS; ++r)

@@ -29,10 +29,13 @@ def one(path):
         return float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
 
     Ss = [int(v) for v in os.environ.get("SS", "3,5,8,10").split(",")]
-    for C, T, n in ((1024, 10_000_000, 30), (2400, 72_000, 50)):
+    shapes = ((1024, 10_000_000, 30), (2400, 72_000, 50), (96, 72_000, 50), (10_000, 20_000, 50))
+    if os.environ.get("SMALL_ONLY") == "1":
+        shapes = shapes[1:]
+    for C, T, n in shapes:
         cs = synth.generate(C, T, seed=5)
         out = torch.empty_like(cs.data)
-        for S in (Ss if T > 1_000_000 else Ss[:1]):
+        for S in (Ss if T > 1_000_000 else Ss[:2]):
             plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(S))
             enc = plan.alloc_encoded()
             e = timed(lambda: plan.encode(cs.data, out=enc), n)
