@@ -322,10 +322,25 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
     // only whole, 256-byte-aligned blocks go to HBM (16 B per lane, non-temporal); the rest waits
     const uint32_t total = pend + hw + nw;
     const uint32_t nflush = total & ~63u;
-    if (ABL < 1)
-        for (uint32_t i = lane * 4; i < nflush; i += 256)
-            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(buf + i),
-                                        reinterpret_cast<u32x4_u *>(dst + i));
+    // (ABL 8 only; an offset, not a rebuilt pointer -- that would turn the store into a FLAT access)
+    const ptrdiff_t back_abl = (ptrdiff_t)((reinterpret_cast<uintptr_t>(dst) & (uintptr_t)32767) >> 2);
+    if (ABL < 1 || ABL >= 5) {
+        for (uint32_t i = lane * 4; i < nflush; i += 256) {
+            const u32x4 blk = *reinterpret_cast<const u32x4 *>(buf + i);
+            u32x4_u *to = reinterpret_cast<u32x4_u *>(dst + i);
+            // (tuning builds: ABL 5..7 time other flavours of this store -- plain, nt + sc1, sc0 sc1; 8 issues
+            // the same stores but keeps them inside one L2-resident 4 KiB per wave: no DRAM writes)
+            if (ABL == 8) to = reinterpret_cast<u32x4_u *>(dst - back_abl + (i & 1023u));
+            if (ABL == 5 || ABL == 8)
+                *to = blk;
+            else if (ABL == 6)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(to), "v"(blk) : "memory");
+            else if (ABL == 7)
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(to), "v"(blk) : "memory");
+            else
+                __builtin_nontemporal_store(blk, to);
+        }
+    }
     const uint32_t tail = total - nflush;
     uint32_t t = 0;
     if ((uint32_t)lane < tail) t = buf[nflush + lane];
@@ -365,7 +380,7 @@ __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t 
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
 #define MH_FLUSH()                                               \
     if (nb >= 32) {                                              \
-        if (ABL < 3 && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
+        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
         acc >>= 32;                                              \
         nb -= 32;                                                \
         ++sp;                                                    \
@@ -416,7 +431,7 @@ __device__ __forceinline__ void encode_row_packed(typename RawPiece<PK>::type r,
 {
 #define MH_FLUSH()                                               \
     if (nb >= 32) {                                              \
-        if (ABL < 3 && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
+        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
         acc >>= 32;                                              \
         nb -= 32;                                                \
         ++sp;                                                    \
@@ -482,7 +497,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
 #define MH_FLUSH()                                               \
     if (nb >= 32) {                                              \
-        if (ABL < 3 && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
+        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
         acc >>= 32;                                              \
         nb -= 32;                                                \
         ++sp;                                                    \
@@ -540,7 +555,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
         }
     }
 #undef MH_FLUSH
-    if (ABL >= 2) {  // keep the work alive, skip the rest
+    if (ABL >= 2 && ABL < 5) {  // keep the work alive, skip the rest
         words = 0;
         bits = (uint32_t)acc + nb + sp;
         return;
@@ -675,7 +690,7 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
         pend = r.z;
         out += r.w;
     }
-    if (ABL < 1 && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
+    if ((ABL < 1 || ABL >= 5) && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
     if (lane == 0) {
         e.seg_words[seg] = words;
         if (!PRE || e.cal_mode == 0) atomicAdd(&e.ch_bits[ch], (unsigned long long)bits);  // zeroed by k_calibrate
@@ -735,7 +750,13 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
 // so a workgroup packs segments of four different channels and no wave idles.  One 32-byte record
 // per wave task (the planner orders them longest first) replaces the task -> segment -> channel
 // chain of dependent loads, and the segment's first rows are requested before the tables are built.
-__host__ __device__ inline uint32_t enc2w_wave_dwords(uint32_t stage_dw) { return kEncSharedDw + enc2_wave_dwords(stage_dw); }
+// (a wave's tables: the pair table has 4^PB entries -- 64 for S <= 8 -- plus the 16 single-symbol entries; the
+// four-symbol table of 2-bit input has 256.  Sized exactly: with 3-bit pairs four workgroups fit a CU at the
+// largest staging as well.)
+template <int PB, int PK>
+__host__ __device__ constexpr uint32_t enc2w_table_dwords() { return (PK == 2 ? 512u : 2u << (2 * PB)) + 32u; }
+template <int PB, int PK>
+__host__ __device__ inline uint32_t enc2w_wave_dwords(uint32_t stage_dw) { return enc2w_table_dwords<PB, PK>() + enc2_wave_dwords(stage_dw); }
 
 template <int LC, int PB, int PK = 0>
 __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
@@ -746,9 +767,10 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
     if (slot >= a.t.ntask) return;
     const WaveTask t = a.t.wt[slot];
     const uint32_t cap = a.e.stage_dw;
-    uint32_t *wbase = smem + (size_t)wave * enc2w_wave_dwords(cap);
+    constexpr uint32_t kTabDw = enc2w_table_dwords<PB, PK>();
+    uint32_t *wbase = smem + (size_t)wave * enc2w_wave_dwords<PB, PK>(cap);
     uint2 *lut2 = reinterpret_cast<uint2 *>(wbase);
-    uint2 *lut1 = reinterpret_cast<uint2 *>(wbase + 512);
+    uint2 *lut1 = reinterpret_cast<uint2 *>(wbase + kTabDw - 32);
     const uint8_t *src = a.e.data + t.src_off;  // the planner's records hold byte offsets of the plan's input packing
     typename RawPiece<PK>::type v[kWin];
     uint2 el = make_uint2(0u, 0u);  // the 16 single-symbol entries {bit-reversed code, length}, one per lane
@@ -833,7 +855,7 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
     uint64_t bits = 0;
     if (t.n)
         encode_segment<LC, PB, 0, true, PK>(a.e, t.seg, t.ch, src, t.n, a.e.payload + t.dst_off, v, lut2, lut1,
-                                            wbase + kEncSharedDw, cap, lane, bits);
+                                            wbase + kTabDw, cap, lane, bits);
     if (a.e.cal_mode != 0 && lane == 0) {
         // Bit total of the channel without a zeroing launch: every record adds {bits << 24 | 1} to the
         // channel's word in plan scratch with ONE returning device-scope atomic.  The record that sees

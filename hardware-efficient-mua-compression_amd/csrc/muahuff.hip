@@ -208,7 +208,7 @@ static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 template <int LC, int PB, int PK = 0>
 static int launch_encode2w(const mh::Enc2Args &a, hipStream_t st)
 {
-    const size_t lds = 4 * (size_t)mh::enc2w_wave_dwords(a.e.stage_dw) * sizeof(uint32_t);
+    const size_t lds = 4 * (size_t)mh::enc2w_wave_dwords<PB, PK>(a.e.stage_dw) * sizeof(uint32_t);
     auto kern = mh::k_encode2w<LC, PB, PK>;
     if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
     hipLaunchKernelGGL(kern, dim3((a.t.ntask + 3) / 4), dim3(256), lds, st, a);
@@ -279,7 +279,11 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
         case 1: return launch_encode2<0, 3, 1>(a2, st);
         case 2: return launch_encode2<0, 3, 2>(a2, st);
         case 3: return launch_encode2<0, 3, 3>(a2, st);
-        default: return launch_encode2<0, 3, 4>(a2, st);
+        case 4: return launch_encode2<0, 3, 4>(a2, st);
+        case 5: return launch_encode2<0, 3, 5>(a2, st);
+        case 6: return launch_encode2<0, 3, 6>(a2, st);
+        case 7: return launch_encode2<0, 3, 7>(a2, st);
+        default: return launch_encode2<0, 3, 8>(a2, st);
         }
     }
 #endif
