@@ -7,6 +7,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+import muahuff
+if len(sys.argv) > 1:  # another build of the library (same-box A/B)
+    muahuff._lib.use_library(os.path.abspath(sys.argv[1]))
 from muahuff import sclv
 from muahuff.stream import StreamEncoder
 
