@@ -912,6 +912,37 @@ def test_short_channels_training_set_shape(mh, S, h):
     plan.close()
 
 
+@pytest.mark.parametrize("h", [4, 8, 12])
+def test_in_wave_calibration_many_encoders_and_long_windows(mh, h):
+    """Short channels calibrate inside the encoding wave (lane k prices encoder k): more encoders than
+    lanes (K = 105, the winners beyond index 64), calibration windows from 16 to 4096 samples -- longer
+    than some of the channels -- and both mappers; (peak, encoder), bits and stream equal the oracle's."""
+    rng = np.random.RandomState(200 + h)
+    lens = [9, 40, 300, 5000, 16384, 16385, 30000, 70001] * 6
+    chans = _channels(rng, lens, 0.05, 5.0)
+    cs = _cs(mh, chans)
+    host = cs.data.cpu().numpy()
+    tab = helpers.sclv_tables()[10]
+    rows = np.ascontiguousarray(np.concatenate([tab[:1]] + [tab[-1:]] * 69 + [tab]))  # winners: row 0 or a row >= 70
+    assert len(rows) == 105
+    for mode in (0, 1):
+        plan = mh.codec.Plan(cs.ch_off, cs.ch_len, 10, h, mode, mh.WIN_AFTER_CAL, rows)
+        p = OC.Params(10, h, mode, OC.WIN_AFTER_CAL, rows, seg_chunks=plan.seg_chunks)
+        e = plan.encode(cs.data)
+        oe = OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+        assert np.array_equal(e.peak.cpu().numpy(), oe["peak"]) and np.array_equal(e.enc.cpu().numpy(), oe["enc"])
+        assert (oe["enc"] >= 64).any() and (oe["enc"] < 64).any()
+        assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+        sw = e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments]
+        assert np.array_equal(sw, oe["seg_words"])
+        out = torch.zeros_like(cs.data)
+        plan.decode(e, out)
+        assert plan.decode_ok()
+        want = OC.decode(oe["payload"], cs.ch_off, cs.ch_len, p, oe["peak"], oe["enc"], len(host), nthreads=8)
+        assert np.array_equal(out.cpu().numpy(), want)
+        plan.close()
+
+
 def test_decoder_never_reads_outside_an_untrusted_payload(mh):
     """mh_decode on garbage: random words, a truncated stream, headers that claim huge chunks, a
     wild segment offset table and out-of-range (peak, encoder) words.  Every launch must finish
