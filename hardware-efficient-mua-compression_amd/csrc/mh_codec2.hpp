@@ -927,6 +927,10 @@ __global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
     }
 }
 
+#ifdef MH_TUNING
+__device__ int d_dec_abl;  // see decode_staged_chunk
+#endif
+
 struct Dec2Args {
     DecArgs d;
     TaskArgs t;
@@ -1095,7 +1099,16 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
             }
             o[d] = w;
         }
-        __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + ((uint32_t)k * kLanes + lane) * MH_PIECE));
+#ifdef MH_TUNING  // timing-only ablation (tools/ablate_decode.py): 1 = every row of a chunk lands on its first KiB
+        const uint32_t krow = d_dec_abl == 1 ? 0u : (uint32_t)k;  // (1/16 of the DRAM writes), 2 = no row stores
+        if (d_dec_abl == 2) {
+            if ((o.x ^ o.y) == 0x12345678u && o.z == 77u) out[0] = 1;
+            return;
+        }
+#else
+        const uint32_t krow = (uint32_t)k;
+#endif
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + (krow * kLanes + lane) * MH_PIECE));
     };
     if (PARTIAL) {  // a rolled loop keeps the rarely run instance small (registers and code)
 #pragma unroll 1

@@ -295,6 +295,17 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
 
 static int dispatch_decode(const mh_plan *p, const mh::Dec2Args &a2, hipStream_t st)
 {
+#ifdef MH_TUNING
+    {
+        static int last = -1;
+        const char *e = getenv("MH_DEC_ABL");
+        const int want = e ? atoi(e) : 0;
+        if (want != last) {
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(mh::d_dec_abl), &want, sizeof(int));
+            last = want;
+        }
+    }
+#endif
     const uint32_t L = p->h.info.maxlen;
     const bool wt = p->h.use_wave_tasks;
     // window maintenance (decode_staged_chunk): 1 = reload, 0 = branchy top-up, 2 = select top-up;
