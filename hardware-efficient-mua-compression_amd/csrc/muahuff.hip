@@ -286,6 +286,14 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
         default: return launch_encode2<0, 3, 8>(a2, st);
         }
     }
+    if (L > 2 && L <= 4 && pb3 && g_ablate) {  // the same for the S = 4..6 kernel (levels 1, 2, 4, 8)
+        switch (g_ablate) {
+        case 1: return launch_encode2<1, 3, 1>(a2, st);
+        case 2: return launch_encode2<1, 3, 2>(a2, st);
+        case 4: return launch_encode2<1, 3, 4>(a2, st);
+        default: return launch_encode2<1, 3, 8>(a2, st);
+        }
+    }
 #endif
     if (L <= 2) return pb3 ? launch_encode2<0, 3>(a2, st) : launch_encode2<0, 4>(a2, st);
     if (L <= 4) return pb3 ? launch_encode2<1, 3>(a2, st) : launch_encode2<1, 4>(a2, st);

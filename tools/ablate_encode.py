@@ -16,14 +16,15 @@ from muahuff import codec, sclv, synth
 
 C, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 10_000_000
 cs = synth.generate(C, T, seed=0)
-plan = codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(3),
+S = int(os.environ.get("S", "3"))  # 3: the S <= 3 kernel, all levels; 5: the S = 4..6 kernel, levels 0, 1, 2, 4, 8
+plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(S),
                   seg_chunks=int(os.environ.get("SEG_CHUNKS", "0")))
 enc = plan.alloc_encoded()
 lib = muahuff._lib.lib()
 names = {0: "full", 1: "no global stores", 2: "+ no scan/merge", 3: "+ no staging writes", 4: "loads only",
          5: "full, plain stores", 6: "full, nt sc1 stores", 7: "full, sc0 sc1 stores", 8: "full, stores kept in L2"}
 for rounds in range(2):
-    for lvl in (0, 1, 2, 4, 5, 6, 7, 8):
+    for lvl in ((0, 1, 2, 4, 5, 6, 7, 8) if S <= 3 else (0, 1, 2, 4, 8)):
         lib.mhdbg_set_ablation(lvl)
         plan.encode(cs.data, out=enc)
         torch.cuda.synchronize()
