@@ -61,7 +61,7 @@ def parse(argv=None):
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-per-S", action="store_true", help="skip the per-dynamic-range sweep (roofline.per_S)")
     ap.add_argument("--no-small-shape", action="store_true", help="skip the short-channel extra (small_shape)")
-    ap.add_argument("--gather-deadline", type=int, default=90, help="seconds allowed for the untimed payload gather")
+    ap.add_argument("--gather-deadline", type=int, default=240, help="seconds allowed for the untimed payload gather")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse "
                     "the multi-rank control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--check-launch", action="store_true",

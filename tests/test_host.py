@@ -117,6 +117,34 @@ def test_plan_argument_errors_without_gpu():
     assert rc == _lib.ERR_SCLV
 
 
+def test_packed_plan_argument_errors_without_gpu():
+    """mh_plan_create_packed refuses layouts the packed kernels cannot read, before it looks for a device:
+    field widths other than 8 / 4 / 2, windows that start inside a channel, S above what 2 bits hold,
+    chunk strides that are not packed / not 16-byte multiples / shorter than a chunk -- and reports the
+    missing device, not a fallback, for a layout it accepts."""
+    import torch
+    L = _lib.lib()
+    h = ct.c_void_p()
+    off, ln = np.zeros(1, np.uint64), np.full(1, 40000, np.uint64)
+    t3, t5 = sclv.table(3), sclv.table(5)
+
+    def create(S, tab, window, bits, stride):
+        return L.mh_plan_create_packed(ct.byref(h), off.ctypes.data, ln.ctypes.data, 1, S, 6, 1, window,
+                                       tab.ctypes.data, len(tab), 0, bits, stride)
+    FULL = muahuff.WIN_FULL
+    assert create(3, t3, FULL, 3, 0) == _lib.ERR_ARG and b"input_bits" in L.mh_last_error()
+    assert create(3, t3, muahuff.WIN_AFTER_CAL, 2, 0) == _lib.ERR_ARG and b"MH_WIN_FULL" in L.mh_last_error()
+    assert create(5, t5, FULL, 2, 0) == _lib.ERR_ARG and b"above 4" in L.mh_last_error()
+    assert create(3, t3, FULL, 8, 4096) == _lib.ERR_ARG and b"chunk_stride" in L.mh_last_error()
+    assert create(3, t3, FULL, 2, 4096 + 8) == _lib.ERR_ARG
+    assert create(3, t3, FULL, 2, 2048) == _lib.ERR_ARG      # a 2-bit chunk is 4096 bytes
+    assert create(5, t5, FULL, 4, 4096) == _lib.ERR_ARG      # a 4-bit chunk is 8192 bytes
+    assert not h.value
+    if not torch.cuda.is_available():
+        assert create(3, t3, FULL, 2, 4096) == _lib.ERR_NO_DEVICE and not h.value
+        assert create(5, t5, FULL, 4, 0) == _lib.ERR_NO_DEVICE and not h.value
+
+
 def test_container_file_roundtrip_without_gpu(tmp_path):
     from muahuff import container_io as cio
     c = cio.Compressed(cio.make_header(3, 6, 1, 2, 2, [[1, 2, 2]]), np.array([100, 7], np.uint64),
