@@ -294,6 +294,27 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
         default: return launch_encode2<1, 3, 8>(a2, st);
         }
     }
+    if (L > 4 && L <= 8 && g_ablate) {  // S = 7, 8 (3-bit pairs) and S = 9 (4-bit pairs): levels 1, 2, 4
+        if (pb3) {
+            switch (g_ablate) {
+            case 1: return launch_encode2<2, 3, 1>(a2, st);
+            case 2: return launch_encode2<2, 3, 2>(a2, st);
+            default: return launch_encode2<2, 3, 4>(a2, st);
+            }
+        }
+        switch (g_ablate) {
+        case 1: return launch_encode2<2, 4, 1>(a2, st);
+        case 2: return launch_encode2<2, 4, 2>(a2, st);
+        default: return launch_encode2<2, 4, 4>(a2, st);
+        }
+    }
+    if (L > 8 && g_ablate) {  // and for the S = 10 kernel (levels 1, 2, 4)
+        switch (g_ablate) {
+        case 1: return launch_encode2<3, 4, 1>(a2, st);
+        case 2: return launch_encode2<3, 4, 2>(a2, st);
+        default: return launch_encode2<3, 4, 4>(a2, st);
+        }
+    }
 #endif
     if (L <= 2) return pb3 ? launch_encode2<0, 3>(a2, st) : launch_encode2<0, 4>(a2, st);
     if (L <= 4) return pb3 ? launch_encode2<1, 3>(a2, st) : launch_encode2<1, 4>(a2, st);
