@@ -180,6 +180,19 @@ __device__ __forceinline__ void pair_entries(uint32_t x, const uint2 *lut2, uint
     }
 }
 
+// ---- the row body of the byte-input encoder -----------------------------------------------------------
+// One 16-sample piece per lane (x = 4 dwords of counts) appended to the lane's 64-bit accumulator.  It exists
+// as MACROS because two functions need the same statements -- encode_full_chunk's unrolled row loop and
+// encode_row for partial chunks -- and routing the hot loop through a function cost the S = 10 kernel 6 %:
+// one source text, two expansions.  The expansion site provides LC, PB, ABL, lut2, acc, nb, sp, st, cap.
+#define MH_FLUSH()                                                                          \
+    if (nb >= 32) {                                                                         \
+        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc;    \
+        acc >>= 32;                                                                         \
+        nb -= 32;                                                                           \
+        ++sp;                                                                               \
+    }
+
 // Short codes (LC 0: max length 2, LC 1: max length 4): the 16 codewords of a piece.  Everything that fits
 // 32 bits is put together in 32-bit arithmetic first -- LC 0: the whole piece (<= 32 bits), LC 1: each half --
 // so the lane's 64-bit accumulator is touched once resp. twice per piece.
@@ -203,6 +216,48 @@ __device__ __forceinline__ void pair_entries(uint32_t x, const uint2 *lut2, uint
             acc |= (uint64_t)h0 << nb; nb += t0 + t1; MH_FLUSH();                      \
             acc |= (uint64_t)h1 << nb; nb += t2 + t3; MH_FLUSH();                      \
         }                                                                              \
+    }
+
+// Long codes: two dwords (8 codewords) share one accumulator check whenever they fit 32 bits in every lane of
+// the wave; otherwise dword by dword, and for 9-bit codes pair by pair (wave-uniform escapes on __any()).
+#define MH_LONG_CODES_ROW(x)                                                                           \
+    _Pragma("unroll") for (int dp = 0; dp < 2; ++dp)                                                   \
+    {                                                                                                  \
+        const uint32_t y0 = pair_index_word<PB>((x)[2 * dp]), y1 = pair_index_word<PB>((x)[2 * dp + 1]); \
+        const uint2 a0 = lut2[y0 & 0xFFu], a1 = lut2[(y0 >> 16) & 0xFFu];                              \
+        const uint2 b0 = lut2[y1 & 0xFFu], b1 = lut2[(y1 >> 16) & 0xFFu];                              \
+        const uint32_t t0 = a0.y + a1.y, t1 = b0.y + b1.y;                                             \
+        if (LC == 3 && __builtin_expect(__any(t0 > 32u || t1 > 32u), 0)) {                             \
+            acc |= (uint64_t)a0.x << nb; nb += a0.y; MH_FLUSH();                                       \
+            acc |= (uint64_t)a1.x << nb; nb += a1.y; MH_FLUSH();                                       \
+            acc |= (uint64_t)b0.x << nb; nb += b0.y; MH_FLUSH();                                       \
+            acc |= (uint64_t)b1.x << nb; nb += b1.y; MH_FLUSH();                                       \
+        } else if (__any(t0 + t1 > 32u)) {                                                             \
+            acc |= (uint64_t)(a0.x | (a1.x << a0.y)) << nb; nb += t0; MH_FLUSH();                      \
+            acc |= (uint64_t)(b0.x | (b1.x << b0.y)) << nb; nb += t1; MH_FLUSH();                      \
+        } else {                                                                                       \
+            const uint32_t q0 = a0.x | (a1.x << a0.y), q1 = b0.x | (b1.x << b0.y);                     \
+            acc |= (uint64_t)(q0 | (q1 << t0)) << nb;                                                  \
+            nb += t0 + t1;                                                                             \
+            MH_FLUSH();                                                                                \
+        }                                                                                              \
+    }
+
+// rare: a count that does not fit PB bits somewhere in this KiB row -> clip the row; then the codewords
+#define MH_ENCODE_ROW(x)                                                                   \
+    {                                                                                      \
+        constexpr uint32_t kHiMask_ = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));          \
+        if (__any((((x).x | (x).y | (x).z | (x).w) & kHiMask_) != 0)) {                    \
+            (x).x = clip_word<PB>((x).x);                                                  \
+            (x).y = clip_word<PB>((x).y);                                                  \
+            (x).z = clip_word<PB>((x).z);                                                  \
+            (x).w = clip_word<PB>((x).w);                                                  \
+        }                                                                                  \
+        if (LC >= 2) {                                                                     \
+            MH_LONG_CODES_ROW(x)                                                           \
+        } else {                                                                           \
+            MH_SHORT_CODES_ROW(x)                                                          \
+        }                                                                                  \
     }
 
 template <int PK>
@@ -369,57 +424,12 @@ __device__ __forceinline__ void overflow_chunk(const uint8_t *src, uint32_t m, c
     dst += words;
 }
 
-// One 16-sample piece per lane (x = 4 dwords of counts) appended to the lane's accumulator: the row
-// body of encode_full_chunk as a function, for the partial-chunk encoder.  (encode_full_chunk keeps its
-// own copy: routing it through this function cost the S=10 kernel 6 % on the same box.)
-// ABL: see encode_full_chunk.
+// The row body as a function, for the partial-chunk encoder (ABL: see encode_full_chunk).
 template <int LC, int PB, int ABL>
 __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t &acc, uint32_t &nb, uint32_t &sp,
                                            uint32_t *st, uint32_t cap)
 {
-    constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
-#define MH_FLUSH()                                               \
-    if (nb >= 32) {                                              \
-        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
-        acc >>= 32;                                              \
-        nb -= 32;                                                \
-        ++sp;                                                    \
-    }
-    const uint32_t hi = (x.x | x.y | x.z | x.w) & kHiMask;
-    if (__any(hi != 0)) {  // rare: a count that does not fit PB bits somewhere in this KiB row
-        x.x = clip_word<PB>(x.x);
-        x.y = clip_word<PB>(x.y);
-        x.z = clip_word<PB>(x.z);
-        x.w = clip_word<PB>(x.w);
-    }
-    if (LC >= 2) {
-        // long codes: two dwords (8 codewords) share one accumulator check whenever they fit 32 bits
-        // in every lane of the wave; otherwise dword by dword, and for 9-bit codes pair by pair
-#pragma unroll
-        for (int dp = 0; dp < 2; ++dp) {
-            const uint32_t y0 = pair_index_word<PB>(x[2 * dp]), y1 = pair_index_word<PB>(x[2 * dp + 1]);
-            const uint2 a0 = lut2[y0 & 0xFFu], a1 = lut2[(y0 >> 16) & 0xFFu];
-            const uint2 b0 = lut2[y1 & 0xFFu], b1 = lut2[(y1 >> 16) & 0xFFu];
-            const uint32_t t0 = a0.y + a1.y, t1 = b0.y + b1.y;
-            if (LC == 3 && __builtin_expect(__any(t0 > 32u || t1 > 32u), 0)) {
-                acc |= (uint64_t)a0.x << nb; nb += a0.y; MH_FLUSH();
-                acc |= (uint64_t)a1.x << nb; nb += a1.y; MH_FLUSH();
-                acc |= (uint64_t)b0.x << nb; nb += b0.y; MH_FLUSH();
-                acc |= (uint64_t)b1.x << nb; nb += b1.y; MH_FLUSH();
-            } else if (__any(t0 + t1 > 32u)) {
-                acc |= (uint64_t)(a0.x | (a1.x << a0.y)) << nb; nb += t0; MH_FLUSH();
-                acc |= (uint64_t)(b0.x | (b1.x << b0.y)) << nb; nb += t1; MH_FLUSH();
-            } else {
-                const uint32_t q0 = a0.x | (a1.x << a0.y), q1 = b0.x | (b1.x << b0.y);
-                acc |= (uint64_t)(q0 | (q1 << t0)) << nb;
-                nb += t0 + t1;
-                MH_FLUSH();
-            }
-        }
-    } else {
-        MH_SHORT_CODES_ROW(x)
-    }
-#undef MH_FLUSH
+    MH_ENCODE_ROW(x)
 }
 
 // The same for a piece of packed input (r = 2 dwords of 4-bit or 1 dword of 2-bit samples): every byte of
@@ -429,13 +439,6 @@ template <int LC, int PK, int ABL>
 __device__ __forceinline__ void encode_row_packed(typename RawPiece<PK>::type r, const uint2 *lut2, uint64_t &acc,
                                                   uint32_t &nb, uint32_t &sp, uint32_t *st, uint32_t cap)
 {
-#define MH_FLUSH()                                               \
-    if (nb >= 32) {                                              \
-        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
-        acc >>= 32;                                              \
-        nb -= 32;                                                \
-        ++sp;                                                    \
-    }
     if constexpr (PK == 2) {
         // 16 codewords in four lookups; LC 0 (max length 2): they always fit one dword, LC 1 (<= 4): 8 do
         const uint32_t y = packed_index_word<2>(r);
@@ -473,7 +476,6 @@ __device__ __forceinline__ void encode_row_packed(typename RawPiece<PK>::type r,
             }
         }
     }
-#undef MH_FLUSH
 }
 
 // One full chunk.  v[] is a rolling window: row k of this chunk sits in v[k & 7]; after it is
@@ -494,14 +496,6 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     uint64_t acc = 0;
     uint32_t nb = 0, sp = 0;
     uint32_t *st = stage_lane_base(buf, cap, lane);
-    constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
-#define MH_FLUSH()                                               \
-    if (nb >= 32) {                                              \
-        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc; \
-        acc >>= 32;                                              \
-        nb -= 32;                                                \
-        ++sp;                                                    \
-    }
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         const typename RawPiece<PK>::type raw = v[k & (kWin - 1)];
@@ -519,42 +513,8 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
             acc += x.x ^ x.y ^ x.z ^ x.w;
             continue;
         }
-        const uint32_t hi = (x.x | x.y | x.z | x.w) & kHiMask;
-        if (__any(hi != 0)) {  // rare: a count that does not fit PB bits somewhere in this KiB row
-            x.x = clip_word<PB>(x.x);
-            x.y = clip_word<PB>(x.y);
-            x.z = clip_word<PB>(x.z);
-            x.w = clip_word<PB>(x.w);
-        }
-        if (LC >= 2) {
-            // long codes: two dwords (8 codewords) share one accumulator check whenever they fit 32 bits
-            // in every lane of the wave; otherwise dword by dword, and for 9-bit codes pair by pair
-#pragma unroll
-            for (int dp = 0; dp < 2; ++dp) {
-                const uint32_t y0 = pair_index_word<PB>(x[2 * dp]), y1 = pair_index_word<PB>(x[2 * dp + 1]);
-                const uint2 a0 = lut2[y0 & 0xFFu], a1 = lut2[(y0 >> 16) & 0xFFu];
-                const uint2 b0 = lut2[y1 & 0xFFu], b1 = lut2[(y1 >> 16) & 0xFFu];
-                const uint32_t t0 = a0.y + a1.y, t1 = b0.y + b1.y;
-                if (LC == 3 && __builtin_expect(__any(t0 > 32u || t1 > 32u), 0)) {
-                    acc |= (uint64_t)a0.x << nb; nb += a0.y; MH_FLUSH();
-                    acc |= (uint64_t)a1.x << nb; nb += a1.y; MH_FLUSH();
-                    acc |= (uint64_t)b0.x << nb; nb += b0.y; MH_FLUSH();
-                    acc |= (uint64_t)b1.x << nb; nb += b1.y; MH_FLUSH();
-                } else if (__any(t0 + t1 > 32u)) {
-                    acc |= (uint64_t)(a0.x | (a1.x << a0.y)) << nb; nb += t0; MH_FLUSH();
-                    acc |= (uint64_t)(b0.x | (b1.x << b0.y)) << nb; nb += t1; MH_FLUSH();
-                } else {
-                    const uint32_t q0 = a0.x | (a1.x << a0.y), q1 = b0.x | (b1.x << b0.y);
-                    acc |= (uint64_t)(q0 | (q1 << t0)) << nb;
-                    nb += t0 + t1;
-                    MH_FLUSH();
-                }
-            }
-        } else {
-            MH_SHORT_CODES_ROW(x)
-        }
+        MH_ENCODE_ROW(x)
     }
-#undef MH_FLUSH
     if (ABL >= 2 && ABL < 5) {  // keep the work alive, skip the rest
         words = 0;
         bits = (uint32_t)acc + nb + sp;
@@ -805,7 +765,7 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
         const uint8_t *cal = a.e.data + (preset ? (t.src_off & ~(uint64_t)15) : t.cal_off);
         const uint32_t cal_n = preset ? 1u : t.cal_n;
         const uint8_t *pk = preset ? a.e.peak_in + t.ch : cal, *en = preset ? a.e.enc_in + t.ch : cal;
-        const CalLoads cl = wave_calibrate_issue(cal, cal_n, S, K, a.e.sclv, lane);
+        const CalLoads cl = wave_calibrate_issue(cal, cal_n, K, a.e.sclv16, lane);
         const int pi = *pk;
         const uint32_t ki = *en;
         first_rows();

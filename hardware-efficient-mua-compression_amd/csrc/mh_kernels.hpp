@@ -297,6 +297,7 @@ struct EncArgs {
     uint32_t cal_mode;
     uint32_t S, mode, K;
     const uint8_t *sclv;          // K*S lengths
+    const uint32_t *sclv16;       // the same rows padded to 16 bytes (4 dwords per row)
     const uint32_t *codes;        // K*16 bit-reversed code | len << 16, by rank
     const uint8_t *peak_in, *enc_in;
     uint8_t *peak_out, *enc_out, *skip_out;  // published by the channel's first record; may be NULL
@@ -312,21 +313,20 @@ struct EncArgs {
 // Split in two so that the caller can put its own (long) loads between the halves: the vector-memory counter
 // retires in order, so what the calibration needs is requested FIRST and waited for with the rest in flight.
 struct CalLoads {
-    int v0;                       // sample `lane` of the window (-1 past its end)
-    uint32_t len[MH_LUT_SYMS];    // code lengths of encoder `lane` by rank (lanes >= K: unused)
+    int v0;      // sample `lane` of the window (masked in the second half when past its end)
+    u32x4 len;   // code lengths of encoder `lane` by rank, one byte each (lanes >= K: a valid row, unused)
 };
 
-__device__ __forceinline__ CalLoads wave_calibrate_issue(const uint8_t *x, uint32_t c, int S, uint32_t K,
-                                                         const uint8_t *sclv, int lane)
+__device__ __forceinline__ CalLoads wave_calibrate_issue(const uint8_t *x, uint32_t c, uint32_t K,
+                                                         const uint32_t *sclv16, int lane)
 {
     // unconditional loads from clamped (always valid) addresses; what does not apply is masked in the second
     // half -- a load inside a branch would be waited for on the spot
     CalLoads l;
     const uint32_t i = (uint32_t)lane < c ? (uint32_t)lane : (c ? c - 1 : 0u);
     l.v0 = (int)x[i];
-    const uint32_t row = ((uint32_t)lane < K ? (uint32_t)lane : K - 1) * (uint32_t)S;
-#pragma unroll
-    for (int r = 0; r < MH_LUT_SYMS; ++r) l.len[r] = sclv[row + (uint32_t)(r < S ? r : S - 1)];
+    const uint32_t row = (uint32_t)lane < K ? (uint32_t)lane : K - 1;
+    l.len = *reinterpret_cast<const u32x4 *>(sclv16 + (size_t)row * 4);
     return l;
 }
 
@@ -372,7 +372,7 @@ __device__ __forceinline__ void wave_calibrate_finish(const CalLoads &l, const u
     if ((uint32_t)lane < K) {
         uint32_t cost = 0;
 #pragma unroll
-        for (int r = 0; r < MH_LUT_SYMS; ++r) cost += l.len[r] * sorted[r];  // sorted[] is 0 beyond S
+        for (int r = 0; r < MH_LUT_SYMS; ++r) cost += ((l.len[r >> 2] >> (8 * (r & 3))) & 0xFFu) * sorted[r];  // sorted[] is 0 beyond S
         key = (cost << 8) | (uint32_t)lane;
     }
     for (uint32_t k = 64 + lane; k < K; k += 64) {  // more than 64 encoders: the rest from memory

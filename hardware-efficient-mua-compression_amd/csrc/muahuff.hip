@@ -74,6 +74,7 @@ struct mh_plan {
     // device tables
     uint64_t *d_ch_off = nullptr, *d_ch_len = nullptr, *d_w0 = nullptr, *d_w1 = nullptr;
     uint8_t *d_skip = nullptr, *d_sclv = nullptr;
+    uint32_t *d_sclv16 = nullptr;  // the K rows padded to 16 bytes: one vector load per lane in the in-wave calibration
     uint32_t *d_codes = nullptr;
     uint32_t *d_seg_ch = nullptr;
     uint64_t *d_seg_first = nullptr, *d_seg_n = nullptr, *d_seg_off = nullptr;
@@ -409,7 +410,7 @@ int mh_approx_sort_perm(int S, int peak, uint8_t *idx)
 int mh_plan_destroy(mh_plan *p)
 {
     if (!p) return MH_OK;
-    void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_codes,
+    void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_sclv16, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
                     p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_dtab2, p->d_scan,
@@ -427,6 +428,11 @@ static int plan_upload(mh_plan *p)
     const uint32_t C = H.info.C;
     const bool cal = !H.cal_tile_ch.empty();
     int rc;
+    std::vector<uint32_t> rows16((size_t)H.info.K * 4, 0u);
+    for (uint32_t k = 0; k < H.info.K; ++k)
+        for (uint32_t r = 0; r < H.info.S; ++r)
+            rows16[(size_t)k * 4 + (r >> 2)] |= (uint32_t)H.sclv[(size_t)k * H.info.S + r] << (8 * (r & 3));
+    if ((rc = upload(&p->d_sclv16, rows16))) return rc;
     if ((rc = upload(&p->d_ch_off, H.ch_off)) || (rc = upload(&p->d_ch_len, H.ch_len)) ||
         (rc = upload(&p->d_w0, H.w0)) || (rc = upload(&p->d_w1, H.w1)) || (rc = upload(&p->d_skip, H.skip)) ||
         (rc = upload(&p->d_sclv, H.sclv)) || (rc = upload(&p->d_codes, H.codes)) ||
@@ -634,6 +640,7 @@ static int encode_common(mh_plan *p, const uint8_t *data, uint32_t *payload, uin
     a.mode = p->h.info.mode;
     a.K = p->h.info.K;
     a.sclv = p->d_sclv;
+    a.sclv16 = p->d_sclv16;
     a.codes = p->d_codes;
     a.peak_in = peak_in;
     a.enc_in = enc_in;
