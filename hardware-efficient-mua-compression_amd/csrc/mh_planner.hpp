@@ -105,7 +105,7 @@ struct PlanHost {
 };
 
 struct PlanTuning {  // MH_TUNING builds only; the defaults are the measured best (profiles/README.md)
-    int dec_w_cap = 10;   // index bits of the hybrid pair table
+    int dec_w_cap = 0;    // index bits of the hybrid pair table (0: 10, and 8 for wave-task plans)
     int dec_nr = 31;      // staging registers per lane of the hybrid decoder
     int wave_tasks = -1;  // -1 = planner's rule, 0 / 1 = force
 };
@@ -276,13 +276,15 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
             }
         }
     // decode table: K symbols per lookup, W index bits.  maxlen <= 5: W = K * maxlen (<= 10), every
-    // entry holds K whole codewords; longer codes: hybrid pair table of 10 index bits and 31
+    // entry holds K whole codewords; longer codes (and W capped below 2 * maxlen): hybrid pair table of 10 index bits and 31
     // staging registers, which keeps 4 workgroups per CU (tables + staging <= 40 KiB of LDS).
     p.dec_K = I.maxlen <= 2 ? 4 : 2;
     p.W = p.dec_K * I.maxlen;
     p.dec_NR = 32;
     if (p.dec_K == 2) {
-        uint32_t cap = tune.dec_w_cap >= 8 && tune.dec_w_cap <= 12 ? (uint32_t)tune.dec_w_cap : 10u;
+        // (wave-task plans build the table once per WAVE: 256 entries instead of 1024 cost a few more flagged
+        // entries but a quarter of the build and 3 KiB less LDS per wave -- 2400 x 72 000, S = 8: 66 -> 58 us)
+        uint32_t cap = tune.dec_w_cap >= 8 && tune.dec_w_cap <= 12 ? (uint32_t)tune.dec_w_cap : p.use_wave_tasks ? 8u : 10u;
         if (cap < I.maxlen) cap = I.maxlen;  // a flagged entry still holds its first codeword
         if (p.W > cap) p.W = cap;
         if (p.W < 2 * I.maxlen) p.dec_NR = tune.dec_nr == 32 ? 32 : 31;
