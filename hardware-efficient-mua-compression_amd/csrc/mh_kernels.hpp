@@ -575,10 +575,14 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint64_t *seg_words, u
     if (threadIdx.x == 0) total[0] = run;
 }
 
-// One wave per segment, kCompactSegs segments per workgroup (a segment is only a few KiB: one
-// workgroup per segment is dispatch-bound).  The destination is word-aligned only, so up to 3
+// One wave per segment, kCompactSegs segments per workgroup (a segment is only a few KiB: one workgroup per
+// segment is dispatch-bound; more than one segment per WAVE serialises their round trips -- 16 / 8 / 4 per
+// workgroup: 0.82 / 0.78 / 0.72 ms for 1.85 GB).  The destination is word-aligned only, so up to 3
 // head words are peeled off to make the 16-byte stores aligned; the loads take the misalignment.
-constexpr uint32_t kCompactSegs = 16;
+#ifndef MH_COMPACT_SEGS
+#define MH_COMPACT_SEGS 4
+#endif
+constexpr uint32_t kCompactSegs = MH_COMPACT_SEGS;
 
 __global__ __launch_bounds__(256) void k_compact(const uint32_t *__restrict__ payload, const uint64_t *seg_off,
                                                  const uint64_t *seg_words, const uint64_t *dense_off,
