@@ -5,7 +5,7 @@
 //   k_hist<NS>       window histogram for S <= 3, byte-parallel compares, 16 B/lane reads
 //   k_finalize       rank-map the histogram, bits = SCLV[enc] . post
 //   decode_chunk     per-symbol decoder straight from global memory (partial / oversize chunks)
-//   k_scan_* / k_compact       dense re-packing of the segment slots
+//   k_scan_* / k_compact       dense re-packing of the segment slots (<= 2048 segments: k_compact scans for itself)
 //   k_synth          synthetic MUA generator
 // The encoder / decoder proper are in mh_codec2.hpp, layout kernels in mh_layout.hpp.
 //
@@ -547,34 +547,6 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint64_t *seg_words, u
     }
 }
 
-// <= kScanBlock segments (small recordings, stream blocks): the whole scan in one workgroup and
-// one launch -- these calls are bound by the number of dependent launches, not by bytes
-__global__ __launch_bounds__(256) void k_scan_small(const uint64_t *seg_words, uint64_t nseg, uint64_t *dense_off,
-                                                    uint64_t *total)
-{
-    __shared__ uint64_t wsum[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t run = 0;
-    for (int j = 0; j < 8; ++j) {
-        const uint64_t i = (uint64_t)j * 256 + threadIdx.x;
-        const uint64_t v = i < nseg ? seg_words[i] : 0;
-        uint64_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        __syncthreads();
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint64_t before = 0;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (i < nseg) dense_off[i] = run + before + incl - v;
-        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
-    if (threadIdx.x == 0) total[0] = run;
-}
-
 // One wave per segment, kCompactSegs segments per workgroup (a segment is only a few KiB: one workgroup per
 // segment is dispatch-bound; more than one segment per WAVE serialises their round trips -- 16 / 8 / 4 per
 // workgroup: 0.82 / 0.78 / 0.72 ms for 1.85 GB).  The destination is word-aligned only, so up to 3
@@ -584,15 +556,38 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint64_t *seg_words, u
 #endif
 constexpr uint32_t kCompactSegs = MH_COMPACT_SEGS;
 
+// SELF_SCAN (<= kScanBlock segments: small recordings, stream blocks): no scan kernels in front -- every wave
+// sums the word counts of the segments before its own (<= 32 loads per lane), writes its dense offset, and the
+// wave of the last segment the total: ONE launch for the whole compaction, which is what such calls are bound by.
+template <bool SELF_SCAN>
 __global__ __launch_bounds__(256) void k_compact(const uint32_t *__restrict__ payload, const uint64_t *seg_off,
-                                                 const uint64_t *seg_words, const uint64_t *dense_off,
-                                                 uint32_t *__restrict__ dense, uint64_t dense_cap, uint64_t nseg)
+                                                 const uint64_t *seg_words, uint64_t *dense_off,
+                                                 uint32_t *__restrict__ dense, uint64_t dense_cap, uint64_t nseg,
+                                                 uint64_t *total)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (SELF_SCAN && nseg == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) total[0] = 0;
+        return;
+    }
     for (uint32_t s = wave; s < kCompactSegs; s += 4) {
         const uint64_t seg = (uint64_t)blockIdx.x * kCompactSegs + s;
         if (seg >= nseg) return;
-        const uint64_t n = seg_words[seg], d0 = dense_off[seg];
+        const uint64_t n = seg_words[seg];
+        uint64_t d0;
+        if (SELF_SCAN) {
+            uint64_t part = 0;
+            for (uint64_t i = lane; i < seg; i += 64) part += seg_words[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+            d0 = part;
+            if (lane == 0) {
+                dense_off[seg] = d0;
+                if (seg + 1 == nseg) total[0] = d0 + n;
+            }
+        } else {
+            d0 = dense_off[seg];
+        }
         if (d0 + n > dense_cap) continue;  // host checks total_words afterwards
         const uint32_t *src = payload + seg_off[seg];  // slots start on 128-byte lines
         uint32_t *dst = dense + d0;

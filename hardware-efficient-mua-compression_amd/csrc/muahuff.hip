@@ -852,22 +852,22 @@ int mh_compact(mh_plan *p, const uint32_t *payload, const uint64_t *seg_words, u
     hipStream_t st = (hipStream_t)stream;
     const uint64_t nseg = p->h.info.n_segments;
     const uint64_t nblocks = (nseg + mh::kScanBlock - 1) / mh::kScanBlock;
-    if (nblocks <= 1) {
-        hipLaunchKernelGGL(mh::k_scan_small, dim3(1), dim3(256), 0, st, seg_words, nseg, dense_off, total_words);
-    } else {
-        hipLaunchKernelGGL(mh::k_scan_block_sums, dim3((unsigned)nblocks), dim3(256), 0, st, seg_words, nseg, p->d_scan);
-        hipLaunchKernelGGL(mh::k_scan_top, dim3(1), dim3(1024), 0, st, p->d_scan, nblocks, total_words);
-        hipLaunchKernelGGL(mh::k_scan_apply, dim3((unsigned)nblocks), dim3(256), 0, st, seg_words, nseg,
-                           (const uint64_t *)p->d_scan, dense_off);
-    }
-    MH_HIP(hipGetLastError());
-    if (nseg) {
-        const uint64_t nwg = (nseg + mh::kCompactSegs - 1) / mh::kCompactSegs;
-        hipLaunchKernelGGL(mh::k_compact, dim3((unsigned)nwg), dim3(256), 0, st, payload,
-                           (const uint64_t *)p->d_seg_off, seg_words, (const uint64_t *)dense_off,
-                           dense, dense_cap_words, nseg);
+    if (nblocks <= 1) {  // one launch: every wave scans for itself
+        const uint64_t nwg = nseg ? (nseg + mh::kCompactSegs - 1) / mh::kCompactSegs : 1;
+        hipLaunchKernelGGL(mh::k_compact<true>, dim3((unsigned)nwg), dim3(256), 0, st, payload,
+                           (const uint64_t *)p->d_seg_off, seg_words, dense_off, dense, dense_cap_words, nseg, total_words);
         MH_HIP(hipGetLastError());
+        return MH_OK;
     }
+    hipLaunchKernelGGL(mh::k_scan_block_sums, dim3((unsigned)nblocks), dim3(256), 0, st, seg_words, nseg, p->d_scan);
+    hipLaunchKernelGGL(mh::k_scan_top, dim3(1), dim3(1024), 0, st, p->d_scan, nblocks, total_words);
+    hipLaunchKernelGGL(mh::k_scan_apply, dim3((unsigned)nblocks), dim3(256), 0, st, seg_words, nseg,
+                       (const uint64_t *)p->d_scan, dense_off);
+    MH_HIP(hipGetLastError());
+    const uint64_t nwg = (nseg + mh::kCompactSegs - 1) / mh::kCompactSegs;
+    hipLaunchKernelGGL(mh::k_compact<false>, dim3((unsigned)nwg), dim3(256), 0, st, payload,
+                       (const uint64_t *)p->d_seg_off, seg_words, dense_off, dense, dense_cap_words, nseg, total_words);
+    MH_HIP(hipGetLastError());
     return MH_OK;
 }
 

@@ -45,7 +45,8 @@ for name, C, T, lo, hi in (("96 ch x 3.6e6 bins (1 ms bins, 1 h)", 96, 3_600_000
         with torch.cuda.graph(g, stream=side):
             step()
         graph = timed(g.replay)
-        meas = timed(lambda: plan.measure(cs.data))
+        m_out = plan.measure(cs.data)  # outputs allocated once: the timed call is the three kernel launches
+        meas = timed(lambda: plan.measure(cs.data, out=m_out))
     n = plan.window_samples
     ok = torch.equal(torch.clamp(cs.data[:C * T].view(C, T)[:, 64:], max=2), out[:C * T].view(C, T)[:, 64:]) if T % 16 == 0 else None
     print("%-52s enc+dec eager %7.1f us  graph %7.1f us (%.1f GSamples/s)  measure %6.1f us  bits/sample %.3f  roundtrip %s"
