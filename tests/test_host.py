@@ -26,6 +26,13 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().mh_version() == 102
 
 
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() compiles (or finds up to date) the library, the
+    plain-C client and the oracle, and checks the library's version against the header."""
+    import __graft_entry__ as g
+    g.build()
+
+
 def test_geometry_constants_match_header():
     hdr = open(os.path.join(ROOT, "include", "muahuff.h")).read()
     for name, val in (("MH_PIECE", _lib.PIECE), ("MH_LANES", _lib.LANES), ("MH_ROWS", _lib.ROWS)):
