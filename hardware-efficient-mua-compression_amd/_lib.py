@@ -83,6 +83,10 @@ def lib():
             raise ImportError(
                 "libmuahuff.so is missing (%s). Build it with `python __graft_entry__.py` or "
                 "`python hardware-efficient-mua-compression_amd/build.py`; there is no CPU fallback." % SO)
+        # torch first: its wheel bundles the HIP runtime, and a process must not end up with two of them -- a
+        # libmuahuff.so loaded before torch binds the system libamdhip64, torch then brings its own, and the
+        # library's runtime finds no device (seen as MH_ERR_NO_DEVICE when build() and smoke() share a process)
+        import torch  # noqa: F401
         l = ct.CDLL(SO)
         for name, (res, args) in PROTOTYPES.items():
             f = getattr(l, name)
