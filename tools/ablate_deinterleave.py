@@ -12,7 +12,8 @@ import torch
 
 import muahuff
 
-muahuff._lib.use_library(importlib.import_module("hardware-efficient-mua-compression_amd.build").build(tuning=True))
+muahuff._lib.use_library(os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else
+                         importlib.import_module("hardware-efficient-mua-compression_amd.build").build(tuning=True))
 lib = muahuff._lib.lib()
 vp = ct.c_void_p
 C, T = 1024, int(os.environ.get("T", "10000000"))
