@@ -1068,6 +1068,12 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
 #else
         const uint32_t krow = (uint32_t)k;
 #endif
+#ifdef MH_TUNING
+        if (d_dec_abl == 3) {  // plain instead of non-temporal row stores
+            *reinterpret_cast<u32x4_u *>(out + (krow * kLanes + lane) * MH_PIECE) = o;
+            return;
+        }
+#endif
         __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + (krow * kLanes + lane) * MH_PIECE));
     };
     if (PARTIAL) {  // a rolled loop keeps the rarely run instance small (registers and code)

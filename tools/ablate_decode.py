@@ -16,13 +16,13 @@ from muahuff import codec, sclv, synth
 C, T = 1024, 10_000_000
 cs = synth.generate(C, T, seed=0)
 out = torch.empty_like(cs.data)
-names = {0: "full", 1: "rows stored onto the chunk's first KiB", 2: "no row stores"}
+names = {0: "full", 1: "rows stored onto the chunk's first KiB", 2: "no row stores", 3: "plain row stores"}
 for S in (3, 5, 8):
     plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(S))
     os.environ["MH_DEC_ABL"] = "0"
     enc = plan.encode(cs.data)
     for rounds in range(2):
-        for lvl in (0, 1, 2):
+        for lvl in (0, 3, 2):
             os.environ["MH_DEC_ABL"] = str(lvl)
             plan.decode(enc, out)
             torch.cuda.synchronize()
