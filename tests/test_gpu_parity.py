@@ -742,6 +742,32 @@ def test_error_paths_with_a_device(mh):
     plan.close()
 
 
+def test_channels_that_end_inside_their_calibration_window(mh):
+    """Every channel shorter than the calibration window: the plan has no segment at all.  Measure reports
+    zero bits, encode / compact / decode are well-defined no-ops (total 0 words, nothing written), and the
+    calibration word is still the oracle's."""
+    rng = np.random.RandomState(77)
+    chans = _channels(rng, [1, 5, 63, 64, 17], 0.2, 3.0)
+    cs = _cs(mh, chans)
+    host = cs.data.cpu().numpy()
+    tab = helpers.sclv_tables()[5]
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, 5, 6, 1, mh.WIN_AFTER_CAL, tab)
+    assert plan.n_segments == 0 and plan.window_samples == 0
+    p = OC.Params(5, 6, 1, OC.WIN_AFTER_CAL, tab, seg_chunks=plan.seg_chunks)
+    oe = OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=2)
+    e = plan.encode(cs.data)
+    assert int(e.ch_bits.sum()) == 0
+    assert np.array_equal(e.peak.cpu().numpy(), oe["peak"]) and np.array_equal(e.enc.cpu().numpy(), oe["enc"])
+    d, tot = plan.compact(e)
+    assert int(tot[0]) == 0
+    out = torch.full_like(cs.data, 0xEE)
+    plan.decode(e, out)
+    assert plan.decode_ok() and bool((out == 0xEE).all())
+    m = plan.measure(cs.data)
+    assert int(m.bits.sum()) == 0
+    plan.close()
+
+
 def test_random_access_decompress_of_selected_channels(mh):
     """The per-channel directory gives random access: decoding a subset equals the same channels of
     the full decode, for every window rule (skipped and empty-window channels included)."""
