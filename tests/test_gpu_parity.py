@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs,
 against the golden fixtures produced by the reference, and -- at BASELINE.json's full size --
 through size-independent properties.  Bit-exact everywhere (integer/byte work)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -612,7 +614,9 @@ def test_stream_blocks_through_the_packed_intermediate(mh, S):
     se = stream.StreamEncoder(C, S, 6, tab)
     peak, enc = se.calibrate(block(64))
     peak, enc = peak.cpu().numpy(), enc.cpu().numpy()
-    for T in (16384 * 9 + 5, 16384 * 2, 16383, 100, 17, 16, 1):
+    # MH_FUZZ_ITERS: one-off campaigns add that many random block lengths (log-uniform up to ~12 chunks)
+    extra = [int(np.exp(rng.uniform(0, np.log(200_000)))) for _ in range(int(os.environ.get("MH_FUZZ_ITERS", "0")))]
+    for T in [16384 * 9 + 5, 16384 * 2, 16383, 100, 17, 16, 1] + extra:
         x = block(T)
         c = se.encode_block(x)
         assert np.array_equal(stream.StreamEncoder.decode_block(c), np.minimum(x, S - 1)), T
