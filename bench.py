@@ -214,6 +214,12 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
     out = torch.empty_like(cs.data)
     e_ms = event_times(lambda: plan.encode(cs.data, out=enc), reps, warm=3)
     d_ms = event_times(lambda: plan.decode(enc, out), reps, warm=3)
+    # the reference's own computation on this shape (calibrate + window histogram + bits, its [c, c+T/2) window)
+    plan_m = codec.Plan(cs.ch_off, cs.ch_len, S, h, mode, muahuff.WIN_REF_HALF, tab)
+    m_out = plan_m.measure(cs.data)
+    m_ms = float(np.median(event_times(lambda: plan_m.measure(cs.data, out=m_out), reps, warm=3)))
+    m_n = plan_m.window_samples
+    plan_m.close()
     n = plan.window_samples
     b = float(enc.ch_bits.sum().item()) / n
     ab = n * (1.0 + b / 8.0)
@@ -223,6 +229,7 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
             "samples": n, "bits_per_sample": b, "encode_us": em * 1e3, "decode_us": dm * 1e3,
             "encode_GBps": ab / em / 1e6, "decode_GBps": ab / dm / 1e6,
             "encode_frac": ab / em / 1e6 / HBM_PEAK_GBS, "decode_frac": ab / dm / 1e6 / HBM_PEAK_GBS,
+            "measure_us": m_ms * 1e3, "measure_GBps": m_n / m_ms / 1e6, "measure_frac": m_n / m_ms / 1e6 / HBM_PEAK_GBS,
             "timing": "HIP events around each op (calibrate/table kernel + codec kernel), median of %d" % reps}
 
 

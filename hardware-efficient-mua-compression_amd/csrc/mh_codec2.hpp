@@ -1500,8 +1500,9 @@ __global__ __launch_bounds__(256) void k_hist2(HistArgs a, uint32_t S)
     if ((uint32_t)tid < S - 1) {  // the top bin is the window length minus the rest (k_finalize)
         const uint32_t v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
         const uint32_t slot = a.tile_slot ? a.tile_slot[tile] : ch;
-        if (v) atomicAdd(&a.hist[(size_t)slot * kHistStride + tid], (unsigned long long)v);
+        if (v) hist_add(&a.hist[(size_t)slot * kHistStride + tid], v, a.tile_cnt != nullptr);
     }
+    measure_tail(a, ch);
 }
 
 // [slot][16] u64 scratch (bins 0..8 counted) -> dense [slot][10], top bin = interval length - rest

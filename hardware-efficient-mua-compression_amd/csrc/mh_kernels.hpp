@@ -39,11 +39,9 @@ struct CalArgs {
     const unsigned long long *pre_hist;
 };
 
-__global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
+// One channel by one wave; every lane returns the channel's (peak, encoder).
+__device__ __forceinline__ void calibrate_channel(const CalArgs &a, uint32_t ch, int lane, int &p_out, uint32_t &k_out)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ch >= a.C) return;
     const int S = (int)a.S;
     const uint64_t T = a.ch_len[ch];
     const uint64_t lim = (uint64_t)1 << a.h;
@@ -129,6 +127,18 @@ __global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
         const uint32_t e = a.codes[best_k * 16 + r];
         a.lut[(size_t)ch * kLut + lane] = make_uint2(e & 0xFFFFu, e >> 16);
     }
+    p_out = p;
+    k_out = best_k;
+}
+
+__global__ __launch_bounds__(256) void k_calibrate(CalArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= a.C) return;
+    int p;
+    uint32_t k;
+    calibrate_channel(a, ch, lane, p, k);
 }
 
 // Encode LUTs from a PRESET per-channel (peak, encoder) word instead of a calibration pass: the
@@ -156,6 +166,49 @@ __global__ __launch_bounds__(256) void k_lut_preset(const uint8_t *peak, const u
     }
 }
 
+struct FinArgs {
+    const unsigned long long *hist;
+    const uint64_t *w0, *w1;
+    const uint8_t *skipflag;
+    const uint8_t *peak, *enc, *sclv;
+    uint32_t C, S, mode;
+    uint64_t *post;   // C*S rank order, may be NULL
+    uint64_t *bits;   // may be NULL
+    uint8_t *skipped; // may be NULL
+};
+
+// Rank-map the window histogram of one channel and price it (one thread).  COHERENT: the counts were added by
+// other workgroups of the SAME launch (fused measure): read them at device scope.
+template <bool COHERENT>
+__device__ __forceinline__ void finalize_channel(const FinArgs &a, uint32_t ch, int p, uint32_t enc)
+{
+    const int S = (int)a.S;
+    const uint64_t n = a.w1[ch] - a.w0[ch];
+    const uint8_t *row = a.sclv + (size_t)enc * S;
+    uint64_t h[MH_LUT_SYMS];
+    uint64_t rest = 0, b = 0;
+#pragma unroll
+    for (int s = 0; s < MH_LUT_SYMS; ++s) {
+        h[s] = 0;
+        if (s < S - 1) {
+            const unsigned long long *q = &a.hist[(size_t)ch * kHistStride + s];
+            h[s] = COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+            rest += h[s];
+        }
+    }
+    for (int k = 0; k < S; ++k) {
+        const int sym = symbol_of_rank((int)a.mode, S, p, k);
+        uint64_t v = n - rest;  // the top bin is the window length minus the rest
+#pragma unroll
+        for (int s = 0; s < MH_LUT_SYMS; ++s)
+            if (s == sym && s < S - 1) v = h[s];
+        if (a.post) a.post[(size_t)ch * S + k] = v;  // get_BR_with_approx_sort.py:193
+        b += (uint64_t)row[k] * v;                    // :289 numerator
+    }
+    if (a.bits) a.bits[ch] = b;
+    if (a.skipped) a.skipped[ch] = a.skipflag[ch];
+}
+
 // ------------------------------------------------------------------------------------------
 // window histogram.  For symbols s = 0..S-2 count the bytes equal to s (the top bin is the
 // window length minus the rest, so no clip pass is needed).  Equality is tested on four
@@ -170,7 +223,46 @@ struct HistArgs {
     const uint32_t *tile_n;
     unsigned long long *hist;    // [slot][16], zeroed before the launch
     const uint32_t *tile_slot;   // histogram slot of each tile; NULL = the tile's channel
+    // Fused measure (mh_measure in ONE launch): the workgroup that adds a channel's LAST tile also calibrates
+    // and prices the channel, then leaves histogram and ticket zero for the next call.  tile_cnt == NULL: off.
+    const uint32_t *tile_cnt;    // tiles per channel (>= 1: channels with an empty window get an empty tile)
+    uint32_t *tile_done;         // [C] arrival tickets, zero between launches
+    CalArgs cal;
+    FinArgs fin;
 };
+
+// the workgroup's contribution to one histogram bin; wait: return only when the add has been performed
+__device__ __forceinline__ void hist_add(unsigned long long *bin, uint32_t v, bool wait)
+{
+    if (!wait) {
+        atomicAdd(bin, (unsigned long long)v);
+        return;
+    }
+    const unsigned long long before = atomicAdd(bin, (unsigned long long)v);
+    asm volatile("" ::"v"(before));  // consume the returned value: the wave waits for it
+}
+
+// call at the very end of a window-histogram kernel, after the workgroup's hist_adds into a.hist
+__device__ __forceinline__ void measure_tail(const HistArgs &a, uint32_t ch)
+{
+    // No fences: the counts travel by device-scope atomics whose RETURN the adding threads have waited for
+    // (hist_add), the ticket is a device-scope atomic, and the last arriver reads the counts with device-scope
+    // atomic loads -- nothing here goes through a cache that would have to be written back or invalidated
+    // (an agent-scope fence per workgroup made this kernel 10x slower).
+    if (!a.tile_cnt) return;
+    __shared__ uint32_t s_last;
+    __syncthreads();   // every count of this workgroup has been added (and acknowledged)
+    if (threadIdx.x == 0) s_last = atomicAdd(&a.tile_done[ch], 1u) + 1u == a.tile_cnt[ch] ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    int p;
+    uint32_t k;
+    calibrate_channel(a.cal, ch, lane, p, k);
+    if (lane == 0) finalize_channel<true>(a.fin, ch, p, k);
+    if (lane < kHistStride) a.hist[(size_t)ch * kHistStride + lane] = 0;  // (read above by lane 0 of this wave)
+    if (lane == 0) a.tile_done[ch] = 0;
+}
 
 template <int NS>
 __device__ __forceinline__ void hist_word(uint32_t x, uint32_t (&acc)[NS])
@@ -240,39 +332,17 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a)
     if (tid < NS) {
         const uint32_t v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
         const uint32_t slot = a.tile_slot ? a.tile_slot[tile] : ch;
-        if (v) atomicAdd(&a.hist[(size_t)slot * kHistStride + tid], (unsigned long long)v);
+        if (v) hist_add(&a.hist[(size_t)slot * kHistStride + tid], v, a.tile_cnt != nullptr);
     }
+    measure_tail(a, ch);
 }
 
-struct FinArgs {
-    const unsigned long long *hist;
-    const uint64_t *w0, *w1;
-    const uint8_t *skipflag;
-    const uint8_t *peak, *enc, *sclv;
-    uint32_t C, S, mode;
-    uint64_t *post;   // C*S rank order, may be NULL
-    uint64_t *bits;   // may be NULL
-    uint8_t *skipped; // may be NULL
-};
 
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a)
 {
     const uint32_t ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= a.C) return;
-    const int S = (int)a.S;
-    const uint64_t n = a.w1[ch] - a.w0[ch];
-    const int p = a.peak[ch];
-    const uint8_t *row = a.sclv + (size_t)a.enc[ch] * S;
-    uint64_t rest = 0, b = 0;
-    for (int s = 0; s < S - 1; ++s) rest += a.hist[(size_t)ch * kHistStride + s];
-    for (int k = 0; k < S; ++k) {
-        const int sym = symbol_of_rank((int)a.mode, S, p, k);
-        const uint64_t v = sym == S - 1 ? n - rest : a.hist[(size_t)ch * kHistStride + sym];
-        if (a.post) a.post[(size_t)ch * S + k] = v;  // get_BR_with_approx_sort.py:193
-        b += (uint64_t)row[k] * v;                    // :289 numerator
-    }
-    if (a.bits) a.bits[ch] = b;
-    if (a.skipped) a.skipped[ch] = a.skipflag[ch];
+    finalize_channel<false>(a, ch, a.peak[ch], a.enc[ch]);
 }
 
 // ------------------------------------------------------------------------------------------

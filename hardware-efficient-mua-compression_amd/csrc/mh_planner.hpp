@@ -15,6 +15,12 @@ namespace mh {
 
 constexpr uint32_t kHistTileBytes = 256 * 16 * 32;  // bytes of one histogram tile (128 KiB)
 constexpr uint64_t kCalDirect = 4096;                // longest calibration window k_calibrate scans itself
+// mh_measure as ONE launch (the workgroup of a channel's last tile finishes the channel) pays two atomic round
+// trips at the end of every workgroup and a serial tail per channel; it wins while the call is bound by its
+// launches: 2400 x 72 000 37 against 41 us, 96 x 72 000 11 against 16 -- but 10 000 x 20 000 56 against 47 us and
+// 1024 x 1e7 0.95 against 0.80 ms.  Hence the two limits.
+constexpr uint32_t kFusedMeasureChannels = 4096;
+constexpr uint64_t kFusedMeasureTiles = 16384;
 constexpr uint64_t kAutoSegLimit = 16384;            // seg_chunks = 0: one-chunk segments below this many two-chunk ones
 
 inline uint32_t bitrev(uint32_t v, int n)
@@ -95,10 +101,11 @@ struct PlanHost {
     // wave tasks of the per-wave-table kernels: every segment once, longest first
     std::vector<WaveTask> wave_tasks;
     bool use_wave_tasks = false;
+    bool measure_fused = false;   // mh_measure in one launch (see kFusedMeasureChannels)
     bool fused_calibration = false;  // wave tasks calibrate in the wave (2^h <= kCalDirect): encode is ONE launch
     bool tickets_fit = false;        // every channel: records < 2^24 and 9 bits/sample * T < 2^40 (the packed total word)
     // window-histogram tiles, calibration tiles (windows above kCalDirect samples)
-    std::vector<uint32_t> tile_ch, tile_n, cal_tile_ch, cal_tile_n;
+    std::vector<uint32_t> tile_ch, tile_n, tile_cnt, cal_tile_ch, cal_tile_n;  // tile_cnt: tiles per channel
     std::vector<uint64_t> tile_start, cal_tile_start;
     // decoder geometry
     uint32_t W = 0, dec_K = 4, dec_NR = 32;
@@ -216,7 +223,16 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
             p.tile_start.push_back(p.w0[c] + first);
             p.tile_n.push_back((uint32_t)(n - first < kHistTileBytes ? n - first : kHistTileBytes));
         }
+        // every channel has at least one tile (an empty one for an empty window): the workgroup of a channel's
+        // last tile finishes the channel when mh_measure runs as one launch
+        if (n == 0) {
+            p.tile_ch.push_back(c);
+            p.tile_start.push_back(p.w0[c]);
+            p.tile_n.push_back(0);
+        }
+        p.tile_cnt.push_back((uint32_t)(n ? (n + kHistTileBytes - 1) / kHistTileBytes : 1));
     }
+    p.measure_fused = ((uint64_t)1 << I.h) <= kCalDirect && C <= kFusedMeasureChannels && p.tile_ch.size() <= kFusedMeasureTiles;
     I.n_segments = p.seg_ch.size();
     I.payload_cap_words = slot + 4;  // decode reads <= 3 words past the last chunk
     // per-wave-table kernels when the shared-table tasks would leave more than 1 wave in 16 idle

@@ -74,7 +74,8 @@ struct mh_plan {
     // device tables
     uint64_t *d_ch_off = nullptr, *d_ch_len = nullptr, *d_w0 = nullptr, *d_w1 = nullptr;
     uint8_t *d_skip = nullptr, *d_sclv = nullptr;
-    uint32_t *d_sclv16 = nullptr;  // the K rows padded to 16 bytes: one vector load per lane in the in-wave calibration
+    uint32_t *d_sclv16 = nullptr;
+    uint32_t *d_tile_cnt = nullptr, *d_tile_done = nullptr;  // fused measure: tiles per channel, arrival tickets  // the K rows padded to 16 bytes: one vector load per lane in the in-wave calibration
     uint32_t *d_codes = nullptr;
     uint32_t *d_seg_ch = nullptr;
     uint64_t *d_seg_first = nullptr, *d_seg_n = nullptr, *d_seg_off = nullptr;
@@ -120,9 +121,37 @@ static int check_device(int device, const char *who)
     return MH_OK;
 }
 
+static mh::CalArgs calibrate_args(const mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
+                                  uint8_t *peak, uint8_t *enc, unsigned long long *zero_hist,
+                                  unsigned long long *zero_bits, uint8_t *skip_dst);
+
 static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
                             uint8_t *peak, uint8_t *enc, hipStream_t st, unsigned long long *zero_hist,
                             unsigned long long *zero_bits, uint8_t *skip_dst)
+{
+    const mh_plan_info_t &I = p->h.info;
+    mh::CalArgs a = calibrate_args(p, data, cutoff, cal_hist, peak, enc, zero_hist, zero_bits, skip_dst);
+    if (!p->h.cal_tile_ch.empty()) {  // long calibration windows (2^h > kCalDirect): tiled histogram first
+        MH_HIP(hipMemsetAsync(p->d_calhist, 0, (size_t)a.C * mh::kHistStride * sizeof(unsigned long long), st));
+        mh::HistArgs ha{};
+        ha.data = data;
+        ha.ch_off = p->d_ch_off;
+        ha.tile_ch = p->d_cal_tile_ch;
+        ha.tile_start = p->d_cal_tile_start;
+        ha.tile_n = p->d_cal_tile_n;
+        ha.hist = p->d_calhist;
+        ha.tile_slot = nullptr;
+        hipLaunchKernelGGL(mh::k_hist2<4>, dim3((unsigned)p->h.cal_tile_ch.size()), dim3(256), 0, st, ha, I.S);
+        a.pre_hist = p->d_calhist;
+    }
+    hipLaunchKernelGGL(mh::k_calibrate, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+}
+
+static mh::CalArgs calibrate_args(const mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_hist,
+                                  uint8_t *peak, uint8_t *enc, unsigned long long *zero_hist,
+                                  unsigned long long *zero_bits, uint8_t *skip_dst)
 {
     const mh_plan_info_t &I = p->h.info;
     mh::CalArgs a;
@@ -146,22 +175,7 @@ static int launch_calibrate(mh_plan *p, const uint8_t *data, uint64_t *cutoff, u
     a.enc = enc;
     a.lut = p->d_lut;
     a.pre_hist = nullptr;
-    if (!p->h.cal_tile_ch.empty()) {  // long calibration windows (2^h > kCalDirect): tiled histogram first
-        MH_HIP(hipMemsetAsync(p->d_calhist, 0, (size_t)a.C * mh::kHistStride * sizeof(unsigned long long), st));
-        mh::HistArgs ha;
-        ha.data = data;
-        ha.ch_off = p->d_ch_off;
-        ha.tile_ch = p->d_cal_tile_ch;
-        ha.tile_start = p->d_cal_tile_start;
-        ha.tile_n = p->d_cal_tile_n;
-        ha.hist = p->d_calhist;
-        ha.tile_slot = nullptr;
-        hipLaunchKernelGGL(mh::k_hist2<4>, dim3((unsigned)p->h.cal_tile_ch.size()), dim3(256), 0, st, ha, I.S);
-        a.pre_hist = p->d_calhist;
-    }
-    hipLaunchKernelGGL(mh::k_calibrate, dim3((a.C + 3) / 4), dim3(256), 0, st, a);
-    MH_HIP(hipGetLastError());
-    return MH_OK;
+    return a;
 }
 
 template <int NS>
@@ -410,7 +424,8 @@ int mh_approx_sort_perm(int S, int peak, uint8_t *idx)
 int mh_plan_destroy(mh_plan *p)
 {
     if (!p) return MH_OK;
-    void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_sclv16, p->d_codes,
+    void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_sclv16, p->d_tile_cnt,
+                    p->d_tile_done, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
                     p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_dtab2, p->d_scan,
@@ -432,7 +447,7 @@ static int plan_upload(mh_plan *p)
     for (uint32_t k = 0; k < H.info.K; ++k)
         for (uint32_t r = 0; r < H.info.S; ++r)
             rows16[(size_t)k * 4 + (r >> 2)] |= (uint32_t)H.sclv[(size_t)k * H.info.S + r] << (8 * (r & 3));
-    if ((rc = upload(&p->d_sclv16, rows16))) return rc;
+    if ((rc = upload(&p->d_sclv16, rows16)) || (rc = upload(&p->d_tile_cnt, H.tile_cnt)) || (rc = alloc(&p->d_tile_done, C))) return rc;
     if ((rc = upload(&p->d_ch_off, H.ch_off)) || (rc = upload(&p->d_ch_len, H.ch_len)) ||
         (rc = upload(&p->d_w0, H.w0)) || (rc = upload(&p->d_w1, H.w1)) || (rc = upload(&p->d_skip, H.skip)) ||
         (rc = upload(&p->d_sclv, H.sclv)) || (rc = upload(&p->d_codes, H.codes)) ||
@@ -531,6 +546,9 @@ int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t
         return fail(MH_ERR_ARG, "mh_plan_create: %zu segments exceed the 32-bit directory", p->h.seg_ch.size());
     }
     int rc = plan_upload(p);
+    if (rc == MH_OK && (hipMemset(p->d_hist, 0, (size_t)I.C * mh::kHistStride * sizeof(unsigned long long)) != hipSuccess ||
+                        hipMemset(p->d_tile_done, 0, (size_t)I.C * sizeof(uint32_t)) != hipSuccess))
+        rc = fail(MH_ERR_HIP, "mh_plan_create: clearing the measure scratch failed");
     if (rc == MH_OK) rc = prepare_kernels(p);
     if (rc != MH_OK) {
         mh_plan_destroy(p);
@@ -568,29 +586,6 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
     if (int rc_ = check_device(p->device, "mh_measure")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     uint8_t *pk = peak ? peak : p->d_peak, *en = enc ? enc : p->d_enc;
-    int rc = launch_calibrate(p, data, cutoff, cal_hist, pk, en, st, p->d_hist, nullptr, nullptr);
-    if (rc) return rc;
-    if (!p->h.tile_ch.empty()) {
-        mh::HistArgs a;
-        a.data = data;
-        a.ch_off = p->d_ch_off;
-        a.tile_ch = p->d_tile_ch;
-        a.tile_start = p->d_tile_start;
-        a.tile_n = p->d_tile_n;
-        a.hist = p->d_hist;
-        a.tile_slot = nullptr;
-        const uint64_t n_tiles = p->h.tile_ch.size();
-        const unsigned nt = (unsigned)n_tiles;
-        if (p->h.info.S == 2)
-            launch_hist<1>(a, n_tiles, st);  // byte-compare kernel: already at the read floor
-        else if (p->h.info.S == 3)
-            launch_hist<2>(a, n_tiles, st);
-        else if (p->h.info.S <= 8)  // pair-LUT histogram, 3-bit pair packing
-            hipLaunchKernelGGL(mh::k_hist2<3>, dim3(nt), dim3(256), 0, st, a, p->h.info.S);
-        else                      // S = 9, 10: 4-bit packing, xor-swizzled
-            hipLaunchKernelGGL(mh::k_hist2<4>, dim3(nt), dim3(256), 0, st, a, p->h.info.S);
-        MH_HIP(hipGetLastError());
-    }
     mh::FinArgs f;
     f.hist = p->d_hist;
     f.w0 = p->d_w0;
@@ -605,6 +600,42 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
     f.post = post_hist;
     f.bits = bits;
     f.skipped = skipped;
+    // Launch-bound shapes (mh_planner.hpp: kFusedMeasureChannels): ONE launch.
+    // The workgroup that adds a channel's last tile to the histogram calibrates and prices the channel
+    // (measure_tail); the histogram scratch and the tickets are left zero for the next call.
+    const bool fused = p->h.measure_fused;
+    if (!fused) {
+        int rc = launch_calibrate(p, data, cutoff, cal_hist, pk, en, st, p->d_hist, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    if (!p->h.tile_ch.empty()) {
+        mh::HistArgs a{};
+        a.data = data;
+        a.ch_off = p->d_ch_off;
+        a.tile_ch = p->d_tile_ch;
+        a.tile_start = p->d_tile_start;
+        a.tile_n = p->d_tile_n;
+        a.hist = p->d_hist;
+        a.tile_slot = nullptr;
+        if (fused) {
+            a.tile_cnt = p->d_tile_cnt;
+            a.tile_done = p->d_tile_done;
+            a.cal = calibrate_args(p, data, cutoff, cal_hist, pk, en, nullptr, nullptr, nullptr);
+            a.fin = f;
+        }
+        const uint64_t n_tiles = p->h.tile_ch.size();
+        const unsigned nt = (unsigned)n_tiles;
+        if (p->h.info.S == 2)
+            launch_hist<1>(a, n_tiles, st);  // byte-compare kernel: already at the read floor
+        else if (p->h.info.S == 3)
+            launch_hist<2>(a, n_tiles, st);
+        else if (p->h.info.S <= 8)  // pair-LUT histogram, 3-bit pair packing
+            hipLaunchKernelGGL(mh::k_hist2<3>, dim3(nt), dim3(256), 0, st, a, p->h.info.S);
+        else                      // S = 9, 10: 4-bit packing, xor-swizzled
+            hipLaunchKernelGGL(mh::k_hist2<4>, dim3(nt), dim3(256), 0, st, a, p->h.info.S);
+        MH_HIP(hipGetLastError());
+    }
+    if (fused) return MH_OK;
     hipLaunchKernelGGL(mh::k_finalize, dim3((f.C + 255) / 256), dim3(256), 0, st, f);
     MH_HIP(hipGetLastError());
     return MH_OK;
@@ -1103,7 +1134,7 @@ int mh_sweep_run(mh_sweep *w, const uint8_t *data, uint64_t *hist, void *stream)
     hipStream_t st = (hipStream_t)stream;
     MH_HIP(hipMemsetAsync(w->d_scratch, 0, (size_t)w->n_slots * mh::kHistStride * sizeof(unsigned long long), st));
     if (w->n_tiles) {
-        mh::HistArgs a;
+        mh::HistArgs a{};
         a.data = data;
         a.ch_off = w->d_ch_off;
         a.tile_ch = w->d_tile_ch;

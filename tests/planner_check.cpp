@@ -99,12 +99,18 @@ int main()
         }
         // histogram tiles cover the windows; calibration tiles cover min(2^h, T) when it is long
         uint64_t tiled = 0;
+        std::vector<unsigned> tiles_of(C, 0);
         for (size_t t = 0; t < p.tile_ch.size(); ++t) {
-            CHECK(p.tile_n[t] > 0 && p.tile_n[t] <= mh::kHistTileBytes);
-            CHECK(p.tile_start[t] + p.tile_n[t] <= p.w1[p.tile_ch[t]]);
+            const unsigned c = p.tile_ch[t];
+            CHECK(c < C && p.tile_n[t] <= mh::kHistTileBytes);
+            CHECK(p.tile_n[t] > 0 || p.w0[c] == p.w1[c]);  // an empty tile only for an empty window
+            CHECK(p.tile_start[t] + p.tile_n[t] <= p.w1[c]);
             tiled += p.tile_n[t];
+            ++tiles_of[c];
         }
         CHECK(tiled == p.info.window_samples);
+        CHECK(p.tile_cnt.size() == C);  // every channel has a tile: its last tile's workgroup finishes the channel
+        for (unsigned c = 0; c < C; ++c) CHECK(tiles_of[c] >= 1 && tiles_of[c] == p.tile_cnt[c]);
         uint64_t cal = 0, cal_want = 0;
         for (size_t t = 0; t < p.cal_tile_ch.size(); ++t) cal += p.cal_tile_n[t];
         if (((uint64_t)1 << h) > mh::kCalDirect)
