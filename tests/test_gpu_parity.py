@@ -746,6 +746,54 @@ def test_error_paths_with_a_device(mh):
     plan.close()
 
 
+@pytest.mark.parametrize("S", [3, 5, 10])
+def test_one_launch_measure_repeats_and_replays(mh, S):
+    """Short recordings take mh_measure as ONE launch (the workgroup of a channel's last histogram tile
+    finishes the channel and leaves the plan's scratch clean): repeated calls, calls interleaved with encode /
+    decode on the same plan, and hipGraph replays all give the oracle's numbers; a layout above the fused
+    limits (more than 4096 channels) gives them through the three-launch path."""
+    rng = np.random.RandomState(300 + S)
+    tab = helpers.sclv_tables()[S]
+    for lens in ([70001, 5, 16384 * 9 + 3, 40000, 200000, 1, 300000] * 3, [700] * 4200):
+        chans = _channels(rng, lens, 0.1, 4.0)
+        cs = _cs(mh, chans)
+        host = cs.data.cpu().numpy()
+        for window in (mh.WIN_REF_HALF, mh.WIN_AFTER_CAL):
+            plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, window, tab)
+            p = OC.Params(S, 6, 1, window, tab, seg_chunks=plan.seg_chunks)
+            om = OC.measure(host, cs.ch_off, cs.ch_len, p)
+
+            def check(m):
+                assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), om["bits"])
+                assert np.array_equal(m.post_hist.cpu().numpy().astype(np.uint64), om["post_mapped"])
+                assert np.array_equal(m.peak.cpu().numpy(), om["peak"]) and np.array_equal(m.enc.cpu().numpy(), om["enc"])
+                assert np.array_equal(m.skipped.cpu().numpy(), om["skipped"])
+            m = plan.measure(cs.data)
+            check(m)
+            for _ in range(3):
+                m.bits.fill_(-1)
+                plan.measure(cs.data, out=m)
+            check(m)
+            e = plan.encode(cs.data)
+            out = torch.zeros_like(cs.data)
+            plan.decode(e, out)
+            plan.measure(cs.data, out=m)
+            check(m)
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                plan.measure(cs.data, out=m)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    plan.measure(cs.data, out=m)
+                for _ in range(2):
+                    m.bits.fill_(-1)
+                    g.replay()
+                torch.cuda.synchronize()
+            check(m)
+            plan.close()
+
+
 def test_channels_that_end_inside_their_calibration_window(mh):
     """Every channel shorter than the calibration window: the plan has no segment at all.  Measure reports
     zero bits, encode / compact / decode are well-defined no-ops (total 0 words, nothing written), and the
