@@ -833,60 +833,6 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
 // ------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------
-struct Dtab2Args {
-    const uint8_t *peak, *enc, *sclv;
-    const uint32_t *codes;
-    uint32_t C, S, mode, W, K;
-    uint32_t nK;  // encoders in the plan
-    void *dtab2;  // K == 4 plans only: C << W entries uint2 {4 symbol bytes, bits consumed}
-    uint8_t *dtab;  // C*512 per-symbol table: symbol | len << 4, indexed by the next maxlen bits
-    uint8_t *dlen;  // C : max code length of the channel's encoder
-};
-
-// Per-symbol table of every channel, and for K == 4 plans (maxlen <= 2) the 4-symbol table:
-// entry idx = the next W = 8 stream bits, which always hold 4 whole codewords of a complete code
-// -> {symbols spread to bytes, total length}.
-__global__ __launch_bounds__(256) void k_build_dtab2(Dtab2Args a)
-{
-    const uint32_t ch = blockIdx.x;
-    const int S = (int)a.S, W = (int)a.W, K = (int)a.K;
-    // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
-    const int p = a.peak[ch] < S ? a.peak[ch] : 0;
-    const uint32_t k = a.enc[ch] < a.nK ? a.enc[ch] : 0;
-    __shared__ uint32_t code[16], clen[16], sym[16];
-    if (threadIdx.x < (uint32_t)S) {
-        const uint32_t c = a.codes[k * 16 + threadIdx.x];
-        code[threadIdx.x] = c & 0xFFFFu;
-        clen[threadIdx.x] = c >> 16;
-        sym[threadIdx.x] = (uint32_t)symbol_of_rank((int)a.mode, S, p, (int)threadIdx.x);
-    }
-    __syncthreads();
-    {   // per-symbol table (partial and oversize chunks)
-        const uint32_t L = clen[S - 1];  // rows are non-decreasing
-        if (threadIdx.x == 0) a.dlen[ch] = (uint8_t)L;
-        for (uint32_t j = threadIdx.x; j < (1u << L); j += 256) {
-            uint8_t e = 0;
-            for (int r = 0; r < S; ++r)
-                if ((j & ((1u << clen[r]) - 1u)) == code[r]) e = (uint8_t)(sym[r] | (clen[r] << 4));
-            a.dtab[(size_t)ch * kDtab + j] = e;
-        }
-    }
-    if (K != 4) return;  // pair tables (K == 2) are derived inside k_decode2 from the per-symbol table
-    for (uint32_t idx = threadIdx.x; idx < (1u << W); idx += 256) {
-        uint32_t pos = 0, bytes = 0;
-        for (int j = 0; j < K; ++j) {
-            int hit = 0;
-            for (int r = 0; r < S; ++r) {
-                const uint32_t l = clen[r];
-                if (((idx >> pos) & ((1u << l) - 1u)) == code[r]) hit = r;
-            }
-            bytes |= sym[hit] << (8 * j);
-            pos += clen[hit];
-        }
-        reinterpret_cast<uint2 *>(a.dtab2)[((size_t)ch << W) + idx] = make_uint2(bytes, pos);
-    }
-}
-
 #ifdef MH_TUNING
 __device__ int d_dec_abl;  // see decode_staged_chunk
 #endif
@@ -894,7 +840,6 @@ __device__ int d_dec_abl;  // see decode_staged_chunk
 struct Dec2Args {
     DecArgs d;
     TaskArgs t;
-    const void *dtab2;
     uint32_t W;  // table index bits
     // per-wave-table kernel: builds its tables itself from the (peak, encoder) word
     const uint8_t *peak, *enc;
@@ -1288,72 +1233,32 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
 #endif
 // Long channels: up to 4 consecutive segments of ONE channel per workgroup, tables shared at LDS
 // address 0 (the kernel has no static LDS; mh_plan_create verifies that from the code object).
-template <int K, int M, int NR, int RL, bool HY>
-__global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
+// The decode tables of channel `ch` built in LDS from its (peak, encoder) word by NT cooperating threads (64: one
+// wave -- the per-wave-table kernel; 256: the workgroup of the shared-table kernel): the 512-byte per-symbol table
+// tab1 and the multi-symbol table tab.  t = index of the thread among the NT, lane = its lane (each wave derives
+// the channel's rank list for itself by shuffles).  Returns the index mask of tab1.
+template <int NT>
+__device__ __forceinline__ void table_sync()
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const uint32_t task = blockIdx.x;
-    const uint32_t seg0 = a.t.task_seg0[task];
-    const uint32_t nseg = a.t.task_n[task];
-    const uint32_t ch = a.d.seg_ch[seg0];
-    const uint32_t W = a.W;
-    constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
-    uint32_t *tab = smem;
-    uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (kEntDw << W));
-    const uint32_t mask1 = (1u << a.d.dlen[ch]) - 1u;
-    if (threadIdx.x < kDtab / 8)
-        reinterpret_cast<uint2 *>(tab1)[threadIdx.x] =
-            reinterpret_cast<const uint2 *>(a.d.dtab + (size_t)ch * kDtab)[threadIdx.x];
-    if (K == 4) {
-        const uint32_t *g = reinterpret_cast<const uint32_t *>(a.dtab2) + (((size_t)ch << W) * kEntDw);
-        for (uint32_t i = threadIdx.x; i < (kEntDw << W); i += 256) tab[i] = g[i];
+    if (NT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     } else {
-        // pair table built in place from the 512-byte per-symbol table (two chained lookups per
-        // entry) instead of streaming 4 << W bytes per workgroup from global memory:
-        // symbol bytes in bits 0-15, bits consumed in 16-30, bit 31 = only one symbol decoded
         __syncthreads();
-        for (uint32_t idx = threadIdx.x; idx < (1u << W); idx += 256) {
-            const uint32_t e1 = tab1[idx & mask1];
-            const uint32_t l1 = e1 >> 4;
-            const uint32_t e2 = tab1[(idx >> l1) & mask1];
-            const uint32_t l2 = e2 >> 4;
-            tab[idx] = l1 + l2 <= W ? (e1 & 15u) | ((e2 & 15u) << 8) | ((l1 + l2) << 16)
-                                    : (e1 & 15u) | (l1 << 16) | 0x80000000u;
-        }
     }
-    __syncthreads();
-    if ((uint32_t)wave >= nseg) return;
-    uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * dec2_stage_dwords(NR);
-    const uint32_t seg = seg0 + (uint32_t)wave;
-    decode_segment<K, M, NR, RL, HY>(a.d, a.d.seg_off[seg], a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg],
-                                     a.d.seg_n[seg], tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
 }
 
-// Short channels: one WAVE per segment of any channel, tables per wave (see k_encode2w).  The wave
-// derives its tables from the channel's (peak, encoder) word and the plan's codebooks itself, so
-// this decode is ONE launch: no table kernel in front of it.
-template <int K, int M, int NR, int RL, bool HY>
-__global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
+template <int K, int NT>
+__device__ __forceinline__ uint32_t build_decode_tables(const Dec2Args &a, uint32_t ch, uint32_t *tab, uint8_t *tab1, int t,
+                                                        int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * 4 + (uint32_t)wave;
-    if (slot >= a.t.ntask) return;
-    const WaveTask t = a.t.wt[slot];
-    const uint32_t W = a.W;
-    const int S = (int)a.S;
-    constexpr uint32_t kEntDw = K == 4 ? 2 : 1;
-    const uint32_t wdw = dec2_shared_dwords(W, K) + dec2_stage_dwords(NR);  // dwords per wave
-    uint32_t *tab = smem + (size_t)wave * wdw;
-    uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (kEntDw << W));
-    const uint64_t pos = a.plan_slots ? t.dst_off : a.d.seg_off[t.seg];
-    // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
     // (<= 4 encoders: the whole code table is one dword per lane, requested together with the channel's word
     // instead of after it -- one memory round trip before the tables instead of two)
     const uint32_t pre = a.codes[(uint32_t)lane < a.nK * 16u ? (uint32_t)lane : 0u];
-    const int pi = a.peak[t.ch];
-    const uint32_t ki = a.enc[t.ch];
+    const int pi = a.peak[ch];
+    const uint32_t ki = a.enc[ch];
+    const int S = (int)a.S;
+    const uint32_t W = a.W;
     const int p = pi < S ? pi : 0;
     const uint32_t k = ki < a.nK ? ki : 0;
     // rank r of the channel's code: bit-reversed code | len << 16 | symbol << 24, one rank per lane
@@ -1368,7 +1273,7 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
     for (int r = 0; r < MH_LUT_SYMS; ++r)
         if (r == S - 1) L = (rk[r] >> 16) & 0xFFu;
     const uint32_t mask1 = (1u << L) - 1u;
-    for (uint32_t j = lane; j < (1u << L); j += 64) {  // per-symbol table: symbol | len << 4
+    for (uint32_t j = (uint32_t)t; j < (1u << L); j += NT) {  // per-symbol table: symbol | len << 4
         uint32_t e = 0;
 #pragma unroll
         for (int r = 0; r < MH_LUT_SYMS; ++r)
@@ -1379,7 +1284,7 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
         tab1[j] = (uint8_t)e;
     }
     if (K == 4) {  // the next W = 8 bits always hold 4 whole codewords -> {symbols spread to bytes, bits}
-        for (uint32_t idx = lane; idx < (1u << W); idx += 64) {
+        for (uint32_t idx = (uint32_t)t; idx < (1u << W); idx += NT) {
             uint32_t bpos = 0, bytes = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1399,9 +1304,8 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
             reinterpret_cast<uint2 *>(tab)[idx] = make_uint2(bytes, bpos);
         }
     } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t idx = lane; idx < (1u << W); idx += 64) {
+        table_sync<NT>();
+        for (uint32_t idx = (uint32_t)t; idx < (1u << W); idx += NT) {
             const uint32_t e1 = tab1[idx & mask1];
             const uint32_t l1 = e1 >> 4;
             const uint32_t e2 = tab1[(idx >> l1) & mask1];
@@ -1410,8 +1314,52 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
                                     : (e1 & 15u) | (l1 << 16) | 0x80000000u;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    table_sync<NT>();
+    return mask1;
+}
+
+template <int K, int M, int NR, int RL, bool HY>
+__global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x;
+    const uint32_t seg0 = a.t.task_seg0[task];
+    const uint32_t nseg = a.t.task_n[task];
+    const uint32_t ch = a.d.seg_ch[seg0];
+    const uint32_t W = a.W;
+    constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
+    uint32_t *tab = smem;
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (kEntDw << W));
+    // tables built by the workgroup itself from the channel's (peak, encoder) word: no table kernel in front of
+    // the decoder, no per-channel tables in global memory
+    const uint32_t mask1 = build_decode_tables<K, 256>(a, ch, tab, tab1, (int)threadIdx.x, lane);
+    if ((uint32_t)wave >= nseg) return;
+    uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * dec2_stage_dwords(NR);
+    const uint32_t seg = seg0 + (uint32_t)wave;
+    decode_segment<K, M, NR, RL, HY>(a.d, a.d.seg_off[seg], a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg],
+                                     a.d.seg_n[seg], tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
+}
+
+// Short channels: one WAVE per segment of any channel, tables per wave (see k_encode2w).  The wave
+// derives its tables from the channel's (peak, encoder) word and the plan's codebooks itself, so
+// this decode is ONE launch: no table kernel in front of it.
+template <int K, int M, int NR, int RL, bool HY>
+__global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * 4 + (uint32_t)wave;
+    if (slot >= a.t.ntask) return;
+    const WaveTask t = a.t.wt[slot];
+    const uint32_t W = a.W;
+    constexpr uint32_t kEntDw = K == 4 ? 2 : 1;
+    const uint32_t wdw = dec2_shared_dwords(W, K) + dec2_stage_dwords(NR);  // dwords per wave
+    uint32_t *tab = smem + (size_t)wave * wdw;
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (kEntDw << W));
+    const uint64_t pos = a.plan_slots ? t.dst_off : a.d.seg_off[t.seg];
+    // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
+    const uint32_t mask1 = build_decode_tables<K, 64>(a, t.ch, tab, tab1, lane, lane);
     const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tab;
     decode_segment<K, M, NR, RL, HY>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
                                      tab + dec2_shared_dwords(W, K), lane);

@@ -466,7 +466,6 @@ struct DecArgs {
     const uint64_t *ch_off, *w0;
     const uint32_t *seg_ch;
     const uint64_t *seg_first, *seg_n, *seg_off;
-    const uint8_t *dtab, *dlen;
     uint8_t *out;
     uint32_t nseg;
     // every read of the stream stays below payload + payload_words whatever the stream holds; a

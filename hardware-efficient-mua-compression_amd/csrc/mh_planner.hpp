@@ -21,7 +21,11 @@ constexpr uint64_t kCalDirect = 4096;                // longest calibration wind
 // 1024 x 1e7 0.95 against 0.80 ms.  Hence the two limits.
 constexpr uint32_t kFusedMeasureChannels = 4096;
 constexpr uint64_t kFusedMeasureTiles = 16384;
-constexpr uint64_t kAutoSegLimit = 16384;            // seg_chunks = 0: one-chunk segments below this many two-chunk ones
+// seg_chunks = 0: two chunks per segment, one when that would leave fewer than this many segments (not enough
+// waves to fill the part).  encode + decode in us, one / two chunks per segment (tools/small_shape_probe.py):
+// 300 x 72 000 (900 two-chunk segments) 29 / 35, 600 x 72 000 (1800) 37 / 42, 1344 x 72 000 (4032) 60 / 58,
+// 2400 x 72 000 (7200) 91 / 91, 10 000 x 20 000 (10 000) 130 / 120, 96 x 3.6e6 (10 560) 209 / 169.
+constexpr uint64_t kAutoSegLimit = 3072;
 
 inline uint32_t bitrev(uint32_t v, int n)
 {

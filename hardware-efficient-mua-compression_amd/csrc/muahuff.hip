@@ -83,7 +83,7 @@ struct mh_plan {
     uint64_t *d_tile_start = nullptr;
     // device scratch
     unsigned long long *d_hist = nullptr;
-    uint8_t *d_peak = nullptr, *d_enc = nullptr, *d_dtab = nullptr, *d_dlen = nullptr;
+    uint8_t *d_peak = nullptr, *d_enc = nullptr;
     uint2 *d_lut = nullptr;
     // shared-table kernels: workgroup tasks (first segment, count); per-wave-table kernels: the
     // segment of every wave task
@@ -95,7 +95,6 @@ struct mh_plan {
     uint32_t *d_cal_tile_ch = nullptr, *d_cal_tile_n = nullptr;
     uint64_t *d_cal_tile_start = nullptr;
     unsigned long long *d_calhist = nullptr;
-    uint2 *d_dtab2 = nullptr;  // 4-symbol decode tables (dec_K == 4 plans only)
     unsigned long long *d_acc = nullptr;  // wave-task encoder: per-channel {bits << 24 | finished records} (zero between launches)
     uint32_t *d_err = nullptr;  // decode status word (mh_decode_status): epoch of the last failed decode
     uint32_t epoch = 0;         // number of mh_decode calls on this plan
@@ -427,8 +426,8 @@ int mh_plan_destroy(mh_plan *p)
     void *ptrs[] = {p->d_ch_off, p->d_ch_len, p->d_w0, p->d_w1, p->d_skip, p->d_sclv, p->d_sclv16, p->d_tile_cnt,
                     p->d_tile_done, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
-                    p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc, p->d_dtab,
-                    p->d_dlen, p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_dtab2, p->d_scan,
+                    p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc,
+                    p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_scan,
                     p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err, p->d_acc};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -456,11 +455,9 @@ static int plan_upload(mh_plan *p)
         (rc = upload(&p->d_tile_ch, H.tile_ch)) || (rc = upload(&p->d_tile_n, H.tile_n)) ||
         (rc = upload(&p->d_tile_start, H.tile_start)) ||
         (rc = alloc(&p->d_hist, (size_t)C * mh::kHistStride)) || (rc = alloc(&p->d_peak, C)) ||
-        (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_dtab, (size_t)C * mh::kDtab)) ||
-        (rc = alloc(&p->d_dlen, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
+        (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
         (rc = upload(&p->d_task_seg0, H.task_seg0)) || (rc = upload(&p->d_task_n, H.task_n)) ||
         (H.use_wave_tasks && (rc = upload(&p->d_wave_tasks, H.wave_tasks))) ||
-        (H.dec_K == 4 && (rc = alloc(&p->d_dtab2, (size_t)C << H.W))) ||
         (rc = alloc(&p->d_scan, H.seg_ch.size() / mh::kScanBlock + 2)) || (rc = upload(&p->d_err, std::vector<uint32_t>(1, 0u))) ||
         (H.use_wave_tasks && (rc = upload(&p->d_acc, std::vector<unsigned long long>(C, 0ull)))) ||
         (cal && ((rc = upload(&p->d_cal_tile_ch, H.cal_tile_ch)) || (rc = upload(&p->d_cal_tile_n, H.cal_tile_n)) ||
@@ -756,8 +753,6 @@ int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const
     a.seg_first = p->d_seg_first;
     a.seg_n = p->d_seg_n;
     a.seg_off = seg_off ? seg_off : p->d_seg_off;
-    a.dtab = p->d_dtab;
-    a.dlen = p->d_dlen;
     a.out = out;
     a.nseg = (uint32_t)p->h.info.n_segments;
     a.payload_words = payload_words;
@@ -766,7 +761,6 @@ int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const
     mh::Dec2Args a2;
     a2.d = a;
     a2.t = task_args(p);
-    a2.dtab2 = p->d_dtab2;
     a2.W = p->h.W;
     a2.peak = peak;
     a2.enc = enc;
@@ -775,23 +769,7 @@ int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const
     a2.mode = p->h.info.mode;
     a2.nK = p->h.info.K;
     a2.plan_slots = seg_off ? 0u : 1u;
-    if (p->h.use_wave_tasks) return dispatch_decode(p, a2, st);  // builds its tables itself: one launch
-    mh::Dtab2Args t2;
-    t2.peak = peak;
-    t2.enc = enc;
-    t2.sclv = p->d_sclv;
-    t2.codes = p->d_codes;
-    t2.C = p->h.info.C;
-    t2.S = p->h.info.S;
-    t2.mode = p->h.info.mode;
-    t2.W = p->h.W;
-    t2.K = p->h.dec_K;
-    t2.nK = p->h.info.K;
-    t2.dtab2 = p->d_dtab2;
-    t2.dtab = p->d_dtab;
-    t2.dlen = p->d_dlen;
-    hipLaunchKernelGGL(mh::k_build_dtab2, dim3(t2.C), dim3(256), 0, st, t2);
-    MH_HIP(hipGetLastError());
+    // both kernel families build their tables themselves from (peak, enc): one launch
     return dispatch_decode(p, a2, st);
 }
 

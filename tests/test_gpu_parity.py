@@ -948,7 +948,7 @@ def test_plan_parameter_grid_is_accepted_or_rejected_cleanly(mh):
 def test_short_channels_training_set_shape(mh, S, h):
     """The reference's real shape: 50 ms bins give 2e4-7e4 samples per channel and the training set
     holds ~2400 channels (Data/get_all_binned_data.py:16, get_BR_with_approx_sort.py:24,89-90).
-    2400 channels x 72 000 bins: the planner picks one-chunk segments and the per-wave-table
+    2400 channels x 72 000 bins: the planner picks two-chunk segments and the per-wave-table
     kernels (segments of four different channels per workgroup, longest first); measure / encode /
     decode byte-exact against the oracle."""
     C, T = 2400, 72_000
@@ -956,7 +956,7 @@ def test_short_channels_training_set_shape(mh, S, h):
     cs = mh.synth.generate(C, T, seed=5)
     host = cs.data.cpu().numpy()
     plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, mh.MODE_APPROX, mh.WIN_AFTER_CAL, tab)
-    assert plan.seg_chunks == 1 and plan.n_segments == C * 5
+    assert plan.seg_chunks == 2 and plan.n_segments == C * 3   # 4.4 chunks per channel, two per segment
     p = OC.Params(S, h, 1, OC.WIN_AFTER_CAL, tab, seg_chunks=plan.seg_chunks)
     e = plan.encode(cs.data)
     oe = OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=8)

@@ -270,8 +270,10 @@ def test_host_planner_matches_the_oracle_directory_without_a_device():
         assert int(info.payload_cap_words) == want["cap_words"] + 4 and int(info.seg_chunks) == sc
         assert int(info.maxlen) == int(tab.max())
     # seg_chunks = 0: one-chunk segments for small inputs, two-chunk ones for large
+    rc, info, _ = _plan_query([72000] * 600, 3, 6, 1, 2, helpers.sclv_tables()[3], 0)
+    assert rc == 0 and int(info.seg_chunks) == 1 and int(info.n_segments) == 600 * 5   # 1800 two-chunk segments: too few
     rc, info, _ = _plan_query([72000] * 2400, 3, 6, 1, 2, helpers.sclv_tables()[3], 0)
-    assert rc == 0 and int(info.seg_chunks) == 1 and int(info.n_segments) == 2400 * 5
+    assert rc == 0 and int(info.seg_chunks) == 2 and int(info.n_segments) == 2400 * 3
     rc, info, _ = _plan_query([10_000_000] * 64, 3, 6, 1, 2, helpers.sclv_tables()[3], 0)
     assert rc == 0 and int(info.seg_chunks) == 2
     # argument errors come back as codes with a message, never as a crash

@@ -29,7 +29,7 @@ def one(path):
         return float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
 
     Ss = [int(v) for v in os.environ.get("SS", "3,5,8,10").split(",")]
-    shapes = ((1024, 10_000_000, 30), (2400, 72_000, 50), (96, 72_000, 50), (10_000, 20_000, 50))
+    shapes = ((1024, 10_000_000, 30), (2400, 72_000, 50), (96, 72_000, 50), (10_000, 20_000, 50), (96, 3_600_000, 50))
     if os.environ.get("SMALL_ONLY") == "1":
         shapes = shapes[1:]
     for C, T, n in shapes:

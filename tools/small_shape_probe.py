@@ -27,8 +27,8 @@ def timed(f, n=50):
 C, T = int(os.environ.get("C", "2400")), int(os.environ.get("T", "72000"))
 cs = synth.generate(C, T, seed=5)
 out = torch.empty_like(cs.data)
-for S in (3, 5):
-    for sc in (1, 2, 3):
+for S in [int(v) for v in os.environ.get("SS", "3,5").split(",")]:
+    for sc in [int(v) for v in os.environ.get("SC", "1,2,3").split(",")]:
         plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(S), seg_chunks=sc)
         enc = plan.alloc_encoded()
         e = timed(lambda: plan.encode(cs.data, out=enc))
