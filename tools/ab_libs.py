@@ -33,7 +33,8 @@ def one(path):
     if os.environ.get("SMALL_ONLY") == "1":
         shapes = shapes[1:]
     for C, T, n in shapes:
-        cs = synth.generate(C, T, seed=5)
+        lo, hi = [float(v) for v in os.environ.get("RATES", "0.2,3.0").split(",")]  # counts per bin, log-uniform over channels
+        cs = synth.generate(C, T, seed=5, lo=lo, hi=hi)
         out = torch.empty_like(cs.data)
         for S in (Ss if T > 1_000_000 or os.environ.get("SMALL_ONLY") == "1" else Ss[:2]):
             plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(S))
