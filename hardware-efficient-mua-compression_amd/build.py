@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libmuahuff.so")
 SOURCES = ["csrc/muahuff.hip"]
-HEADERS = ["csrc/mh_kernels.hpp", "csrc/mh_device.hpp", "csrc/mh_codec2.hpp", "csrc/mh_layout.hpp",
+HEADERS = ["csrc/exports.map", "csrc/mh_kernels.hpp", "csrc/mh_device.hpp", "csrc/mh_codec2.hpp", "csrc/mh_layout.hpp",
            "csrc/mh_planner.hpp", "csrc/mh_analysis.hpp", "../include/muahuff.h"]
 TUNING_SO = os.path.join(HERE, "libmuahuff_tuning.so")  # -DMH_TUNING: env knobs + ablation hook, tools/ only
 
@@ -34,10 +34,12 @@ def build(force=False, verbose=False, tuning=False):
     elif not force and not stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
     if tuning:
-        cmd.append("-DMH_TUNING")
+        cmd.append("-DMH_TUNING")   # (exports mhdbg_* besides the ABI)
+    else:
+        cmd.append("-Wl,--version-script=" + os.path.join(HERE, "csrc", "exports.map"))
     cmd += [os.path.join(HERE, s) for s in SOURCES] + ["-o", so]
     if verbose:
         print(" ".join(cmd))

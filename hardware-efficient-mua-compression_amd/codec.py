@@ -154,7 +154,8 @@ class Plan:
         return out
 
     def decode_ok(self):
-        """True when the last decode() on this plan stayed inside its payload (synchronises)."""
+        """True when every decode() on this plan since the previous decode_ok() (direct calls and graph
+        replays alike) stayed inside its payload; reading clears the flag (synchronises)."""
         flags = ct.c_uint32(0)
         _lib.check(_lib.lib().mh_decode_status(self._h, ct.byref(flags), _stream()))
         return flags.value == 0

@@ -175,7 +175,7 @@ def validate(c):
         raise ValueError("container header: chunk geometry differs from this library's")
     if not (2 <= S <= 10) or not (1 <= K <= 255) or sclv.min() < 1 or sclv.max() > 9:
         raise ValueError("container header: S / K / code lengths out of range")
-    if not (0 <= h <= 30) or not (0 <= window <= 3) or not (0 <= mode <= 1) or not (1 <= seg_chunks <= 1 << 20):
+    if not (0 <= h <= 30) or not (0 <= window <= 3) or not (0 <= mode <= 1) or not (1 <= seg_chunks <= 0xFFFFFFFF // (_lib.PIECE * _lib.LANES * _lib.ROWS)):
         raise ValueError("container header: h / window / mode / seg_chunks out of range")
     C = len(c.ch_len)
     if not (len(c.peak) == len(c.enc) == len(c.skipped) == len(c.ch_bits) == C):

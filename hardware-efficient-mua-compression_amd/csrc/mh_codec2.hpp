@@ -381,11 +381,17 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
     const ptrdiff_t back_abl = (ptrdiff_t)((reinterpret_cast<uintptr_t>(dst) & (uintptr_t)32767) >> 2);
     if (ABL < 1 || ABL >= 5) {
         for (uint32_t i = lane * 4; i < nflush; i += 256) {
-            const u32x4 blk = *reinterpret_cast<const u32x4 *>(buf + i);
+            u32x4 blk = {0u, 0u, 0u, 0u};
+            if (ABL != 13) blk = *reinterpret_cast<const u32x4 *>(buf + i);
             u32x4_u *to = reinterpret_cast<u32x4_u *>(dst + i);
             // (tuning builds: ABL 5..7 time other flavours of this store -- plain, nt + sc1, sc0 sc1; 8 issues
             // the same stores but keeps them inside one L2-resident 4 KiB per wave: no DRAM writes)
             if (ABL == 8) to = reinterpret_cast<u32x4_u *>(dst - back_abl + (i & 1023u));
+            if (ABL == 13) {  // image merged as usual, but the stores take register data: no ds_read -> store chain
+                const u32x4 junk = {tot, sp, P, (uint32_t)lane};
+                __builtin_nontemporal_store(junk, to);
+                continue;
+            }
             if (ABL == 5 || ABL == 8)
                 *to = blk;
             else if (ABL == 6)
@@ -406,6 +412,20 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
     pend = tail;
     words = hw + nw;
     bits = B;
+}
+
+// Ablation only (tuning builds): the flush of a typical chunk image (736 words = 1.44 bits/sample) with register data
+// instead of the merged image -- same addresses, same block rule as merge_and_flush.
+__device__ __forceinline__ void abl_flush_fixed(uint32_t seed, uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
+                                                uint32_t &words, uint32_t &bits)
+{
+    const uint32_t total = pend + 736u, nflush = total & ~63u;
+    const u32x4 blk = {seed, seed ^ 1u, seed ^ 2u, (uint32_t)lane};
+    for (uint32_t i = lane * 4; i < nflush; i += 256) __builtin_nontemporal_store(blk, reinterpret_cast<u32x4_u *>(dst + i));
+    dst += nflush;
+    pend = total - nflush;
+    words = 736u;
+    bits = 736u * 32u;
 }
 
 // chunk whose sub-streams outgrew the staging: flush the carried tail, then the global slow path
@@ -509,11 +529,15 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
         }
         u32x4 x;
         if constexpr (PK == 0) x = raw;
-        if (ABL == 4) {
+        if (ABL == 4 || ABL == 11) {
             acc += x.x ^ x.y ^ x.z ^ x.w;
             continue;
         }
         MH_ENCODE_ROW(x)
+    }
+    if (ABL == 11 || ABL == 12) {  // 11: loads + a typical chunk's stores (the probe inside the real kernel);
+        abl_flush_fixed((uint32_t)acc + nb + sp, dst, pend, lane, words, bits);  // 12: + the row arithmetic and staging
+        return;
     }
     if (ABL >= 2 && ABL < 5) {  // keep the work alive, skip the rest
         words = 0;
@@ -1114,16 +1138,26 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
     const uint32_t *in = d.payload + pos;
     const uint32_t nfull = (uint32_t)(n / kChunk);
     const uint32_t rem = (uint32_t)(n % kChunk);
+#ifdef MH_DEC_NOCHECK  // A/B builds only: what the bounds checks cost
+#define MH_DEC_BAIL() do { } while (0)
+#else
 #define MH_DEC_BAIL()                              \
     do {                                           \
         if (lane == 0) atomicMax(d.err, d.epoch);  \
         return;                                    \
     } while (0)
+#endif
+    // `need` words readable from word `at` on?  Subtractive, so that a wild 64-bit offset cannot wrap the sum.
+    auto room = [&](uint64_t at, uint64_t need) { return at <= lim && lim - at >= need; };
+    // A full chunk holds 16384 codewords of >= 1 bit: a header that announces fewer than 512 payload words is
+    // corrupt.  (It is also what the prefetch relies on: fetch() and peek() clamp their indices to av - 4 resp.
+    // av - 1, and re-read the chunk's first 4 words once nothing follows -- nw >= 512 keeps all of that inside.)
+    constexpr uint32_t kMinFull = kChunk / 32;
     uint32_t c = 0;  // next chunk the per-symbol loop below would have to decode
     if (nfull) {
-        if (pos + 32 > lim) MH_DEC_BAIL();
+        if (!room(pos, 32)) MH_DEC_BAIL();
         ChunkHdr hc = scan_header(in[lane & 31], lane);  // chunk whose payload is (about to be) in LDS
-        if (pos + hc.hw + hc.nw + 3 + (nfull > 1 ? 32 : 0) > lim) MH_DEC_BAIL();
+        if (hc.nw < kMinFull || !room(pos, (uint64_t)hc.hw + hc.nw + 3 + (nfull > 1 ? 32 : 0))) MH_DEC_BAIL();
         u32x4 R[NV];
         // NV x 1 KiB; lanes past the chunk's own av = nw + 3 words all re-read its last vector (one
         // address: no extra traffic), so the instruction count is fixed but the bytes are the chunk's
@@ -1163,7 +1197,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
             if (nfull > 1) {
                 pos_n += hc.hw + hc.nw;
                 nx = scan_header(hw_next, lane);
-                if (pos_n + nx.hw + nx.nw + 3 + (nfull > 2 ? 32 : 0) > lim) MH_DEC_BAIL();
+                if (nx.nw < kMinFull || !room(pos_n, (uint64_t)nx.hw + nx.nw + 3 + (nfull > 2 ? 32 : 0))) MH_DEC_BAIL();
                 pay_n += hc.nw + nx.hw;
                 avail_n = nx.nw + 3;
                 peek_n = nx.nw + (nfull > 2 ? 32 : 0);
@@ -1197,7 +1231,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
                     pos_n += nx.hw + nx.nw;
                     pay_n += nx.nw;
                     nx = scan_header(hw_next, lane);
-                    if (pos_n + nx.hw + nx.nw + 3 + (c + 2 < nfull ? 32 : 0) > lim) MH_DEC_BAIL();
+                    if (nx.nw < kMinFull || !room(pos_n, (uint64_t)nx.hw + nx.nw + 3 + (c + 2 < nfull ? 32 : 0))) MH_DEC_BAIL();
                     pay_n += nx.hw;
                     avail_n = nx.nw + 3;
                     peek_n = nx.nw + (c + 2 < nfull ? 32 : 0);
@@ -1209,9 +1243,9 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
         }
     }
     for (; c < nfull; ++c) {  // (rest of) a segment that holds an oversize chunk: per-symbol routine
-        if (pos + 32 > lim) MH_DEC_BAIL();
+        if (!room(pos, 32)) MH_DEC_BAIL();
         const ChunkHdr h = scan_header(in[lane & 31], lane);
-        if (pos + h.hw + h.nw + 3 > lim) MH_DEC_BAIL();
+        if (h.nw < kMinFull || !room(pos, (uint64_t)h.hw + h.nw + 3)) MH_DEC_BAIL();
         decode_chunk<3, true>(in, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
         in += h.hw + h.nw;
         pos += h.hw + h.nw;

@@ -145,6 +145,8 @@ inline void channel_window(uint64_t T, uint32_t h, uint32_t window, uint64_t *w0
 
 // Argument checks shared by mh_plan_create and mh_plan_query; returns MH_OK or the error code and
 // a message (static strings with at most one %u).
+constexpr uint32_t kMaxSegChunks = 0xFFFFFFFFu / MH_CHUNK;  // segment sample counts fit 32 bits (WaveTask.n)
+
 inline int plan_check_args(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h, uint32_t mode, uint32_t window,
                            const uint8_t *sclv, uint32_t K, uint32_t *maxlen_out, const char **msg, uint32_t *msg_arg)
 {

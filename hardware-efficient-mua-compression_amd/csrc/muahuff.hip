@@ -14,7 +14,11 @@
 #include "mh_codec2.hpp"
 #include "mh_layout.hpp"
 #include "mh_planner.hpp"
+// The library is built with -fvisibility=hidden: the C ABI of include/muahuff.h is ALL it exports
+// (tests/test_host.py compares the dynamic symbol table with the header's prototypes).
+#pragma GCC visibility push(default)
 #include "muahuff.h"
+#pragma GCC visibility pop
 
 namespace {
 
@@ -96,8 +100,7 @@ struct mh_plan {
     uint64_t *d_cal_tile_start = nullptr;
     unsigned long long *d_calhist = nullptr;
     unsigned long long *d_acc = nullptr;  // wave-task encoder: per-channel {bits << 24 | finished records} (zero between launches)
-    uint32_t *d_err = nullptr;  // decode status word (mh_decode_status): epoch of the last failed decode
-    uint32_t epoch = 0;         // number of mh_decode calls on this plan
+    uint32_t *d_err = nullptr;  // decode status word (mh_decode_status): non-zero once a decode abandoned a segment
 };
 
 struct mh_sweep {
@@ -184,7 +187,7 @@ static void launch_hist(const mh::HistArgs &a, uint64_t n_tiles, hipStream_t st)
 }
 
 #ifdef MH_TUNING
-int g_ablate = 0;  // timing-only ablations of the S <= 3 encoder (mhdbg_set_ablation)
+static int g_ablate = 0;  // timing-only ablations of the S <= 3 encoder (mhdbg_set_ablation)
 #endif
 
 // The launch helpers double as "prepare" helpers: with this thread-local flag set they only
@@ -192,7 +195,7 @@ int g_ablate = 0;  // timing-only ablations of the S <= 3 encoder (mhdbg_set_abl
 // LDS (the decoders address their table by raw LDS offset) and do not launch.  mh_plan_create
 // runs them once that way, so mh_encode / mh_decode issue nothing but stream work and stay
 // capturable into a hipGraph.
-thread_local bool g_prepare_only = false;
+static thread_local bool g_prepare_only = false;
 
 static int prepare_kernel(const void *kern, size_t lds, bool needs_lds_base_0)
 {
@@ -211,7 +214,11 @@ static int prepare_kernel(const void *kern, size_t lds, bool needs_lds_base_0)
 template <int LC, int PB, int ABL = 0, int PK = 0>
 static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
 {
-    const size_t lds = 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw) * sizeof(uint32_t);  // + the static tables
+    size_t lds = 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw) * sizeof(uint32_t);  // + the static tables
+#ifdef MH_TUNING  // occupancy cap through the LDS request (A/B runs)
+    if (const char *e = getenv("MH_ENC_LDS_MIN"))
+        if ((size_t)atoi(e) > lds) lds = (size_t)atoi(e);
+#endif
     auto kern = mh::k_encode2<LC, PB, ABL, PK>;
     if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
     hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
@@ -230,6 +237,8 @@ static int launch_encode2w(const mh::Enc2Args &a, hipStream_t st)
     return MH_OK;
 }
 
+constexpr size_t kDecK4LdsFloor = 41 * 1024;  // 3 workgroups per CU (see launch_decode2)
+
 template <int K, int M, int NR, int RL, bool HY>
 static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st)
 {
@@ -239,7 +248,17 @@ static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st
         if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
         hipLaunchKernelGGL(kern, dim3((a.t.ntask + 3) / 4), dim3(256), lds, st, a);
     } else {
-        const size_t lds = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)mh::dec2_stage_dwords(NR)) * sizeof(uint32_t);
+        const size_t lds_need = ((size_t)mh::dec2_shared_dwords(a.W, K) + 4 * (size_t)mh::dec2_stage_dwords(NR)) * sizeof(uint32_t);
+        size_t lds = lds_need;
+        // The four-symbol decoder (S <= 3) is bound by its 1-KiB row stores, not by its arithmetic, and the part
+        // writes FASTER with fewer waves streaming at once: 3 workgroups per CU instead of the 4 its registers
+        // allow, enforced through the LDS request (160 KiB / 41 KiB = 3): 1024 ch x 1e7 bins decode 2.25 -> 2.04 ms
+        // on one box; 2 per CU: 2.40 ms (profiles/r03_occupancy_ab.txt).  The pair-table decoders (S >= 4) are
+        // bound by their dependent lookup chain and lose with fewer waves (S = 5: 2.27 -> 2.38 ms).
+        if (K == 4 && lds < kDecK4LdsFloor) lds = kDecK4LdsFloor;
+#ifdef MH_TUNING
+        if (const char *e = getenv("MH_DEC_LDS_MIN")) lds = (size_t)atoi(e) > lds_need ? (size_t)atoi(e) : lds_need;
+#endif
         auto kern = mh::k_decode2<K, M, NR, RL, HY>;
         if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, K == 2);
         hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
@@ -297,6 +316,9 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
         case 5: return launch_encode2<0, 3, 5>(a2, st);
         case 6: return launch_encode2<0, 3, 6>(a2, st);
         case 7: return launch_encode2<0, 3, 7>(a2, st);
+        case 11: return launch_encode2<0, 3, 11>(a2, st);
+        case 12: return launch_encode2<0, 3, 12>(a2, st);
+        case 13: return launch_encode2<0, 3, 13>(a2, st);
         default: return launch_encode2<0, 3, 8>(a2, st);
         }
     }
@@ -375,6 +397,7 @@ static int prepare_kernels(const mh_plan *p)
     return rc;
 }
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 int mh_version(void) { return MH_VERSION; }
@@ -474,6 +497,8 @@ static int plan_args(const uint64_t *ch_len, uint32_t C, uint32_t S, uint32_t h,
     uint32_t arg = 0, maxlen = 0;
     const int rc = mh::plan_check_args(ch_len, C, S, h, mode, window, sclv, K, &maxlen, &msg, &arg);
     if (rc != MH_OK) return fail(rc, msg, arg);
+    if (seg_chunks > mh::kMaxSegChunks)  // a wave task counts its samples in 32 bits
+        return fail(MH_ERR_ARG, "seg_chunks=%u above %u", seg_chunks, mh::kMaxSegChunks);
     *I = mh_plan_info_t{};
     I->C = C;
     I->S = S;
@@ -539,8 +564,9 @@ int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t
     p->h.chunk_stride = chunk_stride;
     mh::plan_host_build(p->h, ch_off, ch_len, sclv, plan_tuning());
     if (p->h.seg_ch.size() > 0xFFFFFFF0ull) {  // segment and task indices are 32-bit on the device
+        const size_t nseg = p->h.seg_ch.size();
         mh_plan_destroy(p);
-        return fail(MH_ERR_ARG, "mh_plan_create: %zu segments exceed the 32-bit directory", p->h.seg_ch.size());
+        return fail(MH_ERR_ARG, "mh_plan_create: %zu segments exceed the 32-bit directory", nseg);
     }
     int rc = plan_upload(p);
     if (rc == MH_OK && (hipMemset(p->d_hist, 0, (size_t)I.C * mh::kHistStride * sizeof(unsigned long long)) != hipSuccess ||
@@ -742,6 +768,8 @@ int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const
               const uint8_t *peak, const uint8_t *enc, uint8_t *out, void *stream)
 {
     if (!p || !payload || !peak || !enc || !out) return fail(MH_ERR_ARG, "mh_decode: NULL argument");
+    if (p->h.input_bits != 8)  // a packed plan's offsets describe the packed buffer, not a byte layout to decode into
+        return fail(MH_ERR_ARG, "mh_decode: this plan reads packed pieces (mh_encode_preset only); decode with a byte-layout plan");
     if (int rc_ = check_device(p->device, "mh_decode")) return rc_;
     hipStream_t st = (hipStream_t)stream;
     if (p->h.info.n_segments == 0) return MH_OK;
@@ -757,7 +785,7 @@ int mh_decode(mh_plan *p, const uint32_t *payload, uint64_t payload_words, const
     a.nseg = (uint32_t)p->h.info.n_segments;
     a.payload_words = payload_words;
     a.err = p->d_err;
-    a.epoch = ++p->epoch;
+    a.epoch = 1u;  // the status word is a sticky flag (mh_decode_status reads and clears it)
     mh::Dec2Args a2;
     a2.d = a;
     a2.t = task_args(p);
@@ -780,9 +808,9 @@ int mh_decode_status(mh_plan *p, uint32_t *flags, void *stream)
     uint32_t seen = 0;
     MH_HIP(hipMemcpyAsync(&seen, p->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     MH_HIP(hipStreamSynchronize((hipStream_t)stream));
-    // a failing decode raises the word to its epoch; replays of a captured decode reuse the epoch they
-    // were captured with, so the word is reset once it has been reported
-    *flags = (p->epoch != 0 && seen == p->epoch) ? 1u : 0u;
+    // sticky: any decode since the last status call that abandoned a segment has raised the word -- direct
+    // calls and replays of a captured decode alike (a captured kernel carries no per-call state)
+    *flags = seen ? 1u : 0u;
     if (seen) {
         MH_HIP(hipMemsetAsync(p->d_err, 0, sizeof(uint32_t), (hipStream_t)stream));
         MH_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -1155,3 +1183,4 @@ int mh_reduce_rows(const double *vals, const uint64_t *row_off, uint64_t n_rows,
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

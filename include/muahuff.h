@@ -112,8 +112,9 @@ int mh_plan_create(mh_plan **plan, const uint64_t *ch_off, const uint64_t *ch_le
  * input_bits = 4 or 2 means channel i is ceil(ch_len[i] / 16) pieces of 8 resp. 4 bytes at ch_off[i]
  * (bytes), as mh_deinterleave_packed writes them; input_bits = 8 is mh_plan_create.  Packed plans
  * cover whole channels (MH_WIN_FULL), 2-bit ones need S <= 4, and only mh_encode_preset reads
- * them (a calibrate-then-stream encoder has its (peak, encoder) word already); mh_decode on such a
- * plan writes ordinary bytes.
+ * them (a calibrate-then-stream encoder has its (peak, encoder) word already); mh_measure, mh_encode
+ * and mh_decode return MH_ERR_ARG on such a plan -- its stream decodes with an ordinary byte-layout plan
+ * over the same channel lengths (segment boundaries depend on lengths and seg_chunks only).
  * chunk_stride = 0: a channel's pieces are contiguous.  chunk_stride = B (a multiple of 16, at least
  * one chunk = 1024 pieces): CHUNK-BLOCKED buffer -- the j-th 16384-sample chunk of channel i starts at
  * ch_off[i] + j * B.  With ch_off[i] = i * chunk bytes and B = C * chunk bytes, all channels' chunks
@@ -184,8 +185,10 @@ int mh_encode_preset(mh_plan *plan, const uint8_t *data, const uint8_t *peak, co
  * which also detects inconsistencies that stay inside the buffer. */
 int mh_decode(mh_plan *plan, const uint32_t *payload, uint64_t payload_words, const uint64_t *seg_off,
               const uint8_t *peak, const uint8_t *enc, uint8_t *out, void *stream);
-/* flags (host) <- 0 when the last mh_decode on this plan read only inside its payload, else 1.
- * Synchronises `stream`. */
+/* flags (host) <- 1 when any mh_decode on this plan since the previous mh_decode_status (or since
+ * plan creation) had to abandon a segment, else 0; the flag is cleared by the call.  Sticky on purpose:
+ * replays of a hipGraph that captured mh_decode report through it like direct calls.  Call it after the
+ * decode whose stream you do not trust.  Synchronises `stream`. */
 int mh_decode_status(mh_plan *plan, uint32_t *flags, void *stream);
 
 /* Host-side structural check of a stored stream (no GPU needed; all pointers host): rebuilds the

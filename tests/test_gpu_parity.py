@@ -430,6 +430,58 @@ def test_encode_decode_are_graph_capturable(mh, S):
     plan.close()
 
 
+def test_decode_status_is_sticky_across_graph_replays_and_direct_calls(mh):
+    """A captured decode carries no per-call state, so the status word is a sticky flag: a corrupt stream that
+    goes through a REPLAYED graph is reported even when direct decodes on the same plan happened after the
+    capture (the old epoch scheme reported OK there), and reading the status clears it."""
+    rng = np.random.RandomState(8)
+    chans = _channels(rng, [70000] * 6, 0.2, 3.0)
+    cs = _cs(mh, chans)
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 1, mh.WIN_AFTER_CAL, helpers.sclv_tables()[3])
+    enc = plan.encode(cs.data)
+    good_payload = enc.payload.clone()
+    out = torch.zeros_like(cs.data)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        plan.decode(enc, out)
+    side.synchronize()
+    assert plan.decode_ok()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan.decode(enc, out)
+    for _ in range(3):                      # direct decodes after the capture
+        plan.decode(enc, out)
+    assert plan.decode_ok()
+    enc.payload.fill_(0x7FFFFFFF)           # the buffer the graph reads now holds junk headers
+    g.replay()
+    torch.cuda.synchronize()
+    assert not plan.decode_ok()             # reported ...
+    assert plan.decode_ok()                 # ... and cleared by the read
+    enc.payload.copy_(good_payload)
+    g.replay()
+    torch.cuda.synchronize()
+    assert plan.decode_ok()
+    ref = np.concatenate([np.minimum(x[64:], 2) for x in chans])
+    got = out.cpu().numpy()
+    assert np.array_equal(np.concatenate([got[int(cs.ch_off[c]) + 64:int(cs.ch_off[c]) + len(x)] for c, x in enumerate(chans)]), ref)
+    plan.close()
+
+
+def test_packed_plans_refuse_decode(mh):
+    """mh_decode on a packed-input plan used to derive byte output positions from packed offsets; such plans
+    now refuse measure, encode and decode alike -- their streams decode through a byte-layout plan."""
+    C, T = 8, 40000
+    ch_len = np.full(C, T, np.uint64)
+    ch_off = (np.arange(C) * ((T + 15) // 16 * 8)).astype(np.uint64)
+    plan = mh.codec.Plan(ch_off, ch_len, 5, 0, 1, mh.WIN_FULL, helpers.sclv_tables()[5], input_bits=4)
+    enc = plan.alloc_encoded()
+    out = torch.zeros(int(C * T), dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception) as ei:
+        plan.decode(enc, out)
+    assert "packed" in str(ei.value)
+    plan.close()
+
+
 def test_randomised_design_points_vs_oracle(mh):
     """60 random (S, h, mapper, window, K subset, seg_chunks, ragged lengths, byte offsets):
     measure / encode / decode byte-exact against the CPU oracle."""
@@ -1058,6 +1110,34 @@ def test_decoder_never_reads_outside_an_untrusted_payload(mh):
             wild = torch.full_like(d.seg_off, 2 ** 40)
             pk = torch.full_like(d.peak, 200)
             plan.decode(mh.codec.Encoded(d.payload, d.seg_words, d.ch_bits, pk, pk, d.skipped, wild, True), out)
+            assert not plan.decode_ok()
+            # (5) a payload that was never encoded: every header word is 0 (no sub-stream has a bit), which used to
+            #     send the prefetch's clamped index below zero
+            zeros = torch.zeros_like(d.payload)
+            plan.decode(mh.codec.Encoded(zeros, d.seg_words, d.ch_bits, d.peak, d.enc, d.skipped, d.seg_off, True), out)
+            assert not plan.decode_ok()
+            # (6) a zero header word at the first, a middle and the last full chunk of the long channel's stream
+            seg_off = d.seg_off.cpu().numpy()
+            segs = plan.segments()
+            mine = np.flatnonzero(segs["ch"] == 4)                   # the 200 000-sample channel: 12 full chunks
+            pay_np = d.payload.cpu().numpy().view(np.uint32)
+            starts = []                                              # first header word of every full chunk
+            for sidx in mine:
+                pos, left = int(seg_off[sidx]), int(segs["n"][sidx])
+                while left >= mh.CHUNK:
+                    starts.append(pos)
+                    lens, hw = helpers.chunk_header(pay_np[pos:pos + 32])
+                    pos += hw + (int(lens.sum()) + 31) // 32
+                    left -= mh.CHUNK
+            assert len(starts) == 12
+            for at in (starts[0], starts[len(starts) // 2], starts[-1]):
+                hole = d.payload.clone()
+                hole[at] = 0
+                plan.decode(mh.codec.Encoded(hole, d.seg_words, d.ch_bits, d.peak, d.enc, d.skipped, d.seg_off, True), out)
+                assert not plan.decode_ok()
+            # (7) segment offsets that wrap a 64-bit sum: 2^64 - 16 words
+            wrap = torch.full_like(d.seg_off, -16)
+            plan.decode(mh.codec.Encoded(d.payload, d.seg_words, d.ch_bits, d.peak, d.enc, d.skipped, wrap, True), out)
             assert not plan.decode_ok()
             torch.cuda.synchronize()
             # the plan still decodes the intact stream exactly

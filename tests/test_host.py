@@ -46,6 +46,27 @@ def test_sclv_tables_equal_reference_pickles():
         assert np.array_equal(sclv.table(S), gold[S]), S
 
 
+def test_sclv_generator_reproduces_reference_pickles_in_order(tmp_path):
+    """sclv.generate restates the reference's generator (Compressing data/Produce SCLVs/
+    produce_all_SCLVs_given_S.py:18-29 heap Huffman with list tie-breaks, :55-98 the 0.15-grid odometer with
+    first-seen dedupe): all nine tables, ROW ORDER included (row index = encoder index), equal the rows
+    extracted from the reference's own Stored_SCLVs_S_<S>.pkl (tests/golden/tables.json: sclv)."""
+    gold = helpers.sclv_tables()
+    for S in range(2, 11):
+        got = sclv.generate(S)
+        assert got.dtype == np.uint8 and np.array_equal(got, gold[S]), S
+    # Huffman tie-breaks: equal weights merge in symbol order, a merged entry inherits its lighter half's first symbol
+    assert sclv.huffman_lengths([0.25, 0.25, 0.25, 0.25]) == [2, 2, 2, 2]
+    assert sclv.huffman_lengths([0.5, 0.25, 0.25]) == [1, 2, 2]
+    # symbols 1, 2 merge into a 0.4 entry whose first symbol is 1; the 0.4 LEAF (symbol 0) sorts before it, so the
+    # third 0.2 pairs with the leaf and the tree is balanced -- with the other tie-break it would be [1, 2, 3, 3]
+    assert sclv.huffman_lengths([0.4, 0.2, 0.2, 0.2]) == [2, 2, 2, 2]
+    # a directory in the reference's shape round-trips through the non-executing reader
+    sclv.write_directory(str(tmp_path), {S: sclv.generate(S) for S in (2, 5, 7)})
+    back = sclv.load_directory(str(tmp_path))
+    assert sorted(back) == [2, 5, 7] and all(np.array_equal(back[S], gold[S]) for S in back)
+
+
 def test_codebook_host_helper():
     assert sclv.codewords([1, 2, 2]) == ["0", "10", "11"]  # test_chosen_system.py:26
     assert sclv.codewords([1, 2, 3, 4, 4]) == ["0", "10", "110", "1110", "1111"]
@@ -198,6 +219,12 @@ def test_production_library_has_no_debug_surface():
     """No ablation hook, no environment knobs in the shipped .so (they exist only in -DMH_TUNING builds)."""
     raw = ct.CDLL(_lib.SO)
     assert not hasattr(raw, "mhdbg_set_ablation")
+    # the dynamic symbol table IS the header: no exported globals (g_prepare_only once was one), no
+    # kernel handles, no template instantiations -- csrc/exports.map + -fvisibility=hidden
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.SO], check=True, capture_output=True, text=True).stdout
+    exported = sorted(line.split()[-1] for line in nm.splitlines() if line.strip())
+    assert exported == sorted(_lib.PROTOTYPES), sorted(set(exported) ^ set(_lib.PROTOTYPES))
     blob = open(_lib.SO, "rb").read()
     for name in (b"MH_DEC_W", b"MH_DEC_NR", b"MH_DEC_RELOAD", b"MH_WAVE_TASKS", b"MUAHUFF_LIB"):
         assert name not in blob, name

@@ -22,9 +22,10 @@ plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.tab
 enc = plan.alloc_encoded()
 lib = muahuff._lib.lib()
 names = {0: "full", 1: "no global stores", 2: "+ no scan/merge", 3: "+ no staging writes", 4: "loads only",
-         5: "full, plain stores", 6: "full, nt sc1 stores", 7: "full, sc0 sc1 stores", 8: "full, stores kept in L2"}
+         5: "full, plain stores", 6: "full, nt sc1 stores", 7: "full, sc0 sc1 stores", 8: "full, stores kept in L2",
+         11: "loads + typical stores", 12: "rows+staging + typ. stores", 13: "full, stores from regs"}
 for rounds in range(2):
-    for lvl in ((0, 1, 2, 4, 5, 6, 7, 8) if S <= 3 else (0, 1, 2, 4, 8) if S <= 6 else (0, 1, 2, 4)):
+    for lvl in ((0, 1, 2, 4, 5, 6, 7, 8, 11, 12, 13) if S <= 3 else (0, 1, 2, 4, 8) if S <= 6 else (0, 1, 2, 4)):
         lib.mhdbg_set_ablation(lvl)
         plan.encode(cs.data, out=enc)
         torch.cuda.synchronize()
