@@ -67,6 +67,11 @@ def parse(argv=None):
     ap.add_argument("--check-launch", action="store_true",
                     help="ranks rendezvous, barrier and report; no codec work and no metric (launcher self-test, runs without a GPU)")
     ap.add_argument("--verify", action="store_true", help="round-trip check after the timed region")
+    ap.add_argument("--total-channels", type=int, default=10_000,
+                    help="BASELINE configs[3]: a FIXED set of this many channels x --bins sharded over the ranks "
+                         "(strong scaling, reported as the extra block \"configs3\")")
+    ap.add_argument("--configs3-steps", type=int, default=3)
+    ap.add_argument("--no-configs3", action="store_true", help="skip the configs[3] strong-scaling block")
     return ap.parse_args(argv)
 
 
@@ -233,6 +238,80 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
             "timing": "HIP events around each op (calibrate/table kernel + codec kernel), median of %d" % reps}
 
 
+def configs3_block(a, rank, world, dist, coll_dev, tab):
+    """BASELINE configs[3] / north_star's scaling claim: ONE fixed set of --total-channels channels x --bins
+    (10 000 x 1e7 = 100 GB of counts) sharded in contiguous channel blocks over the ranks -- 1250 channels per GPU
+    at N = 8, all 10 000 on one GPU at N = 1 (100 GB in + 100 GB out + 26 GB of slots fit the 288 GB part) -- so the
+    per-N lines of this block are STRONG scaling of the same job.  Every rank generates its own shard
+    (synth.generate(first_channel=lo): channel c is the same whoever owns it), encodes and decodes it; time =
+    max over ranks, barrier + synchronize on both sides, as for the headline.  Runs after the headline's buffers
+    are free.  -> dict for the JSON line (all ranks must call it; rank 0 uses the result)."""
+    import muahuff
+    from muahuff import codec, dist as mdist, synth
+    S, h, T = a.S, a.hist_bits, a.bins
+    lo, hi = mdist.shard_channels(a.total_channels, world, rank)
+    n_ch = hi - lo
+    # counts + decoded output + slots (maxlen bits per sample, headers, alignment) + slack
+    need = int(n_ch * T * (2.0 + float(tab.max()) / 8.0 * 1.05)) + (2 << 30)
+    free = torch.cuda.mem_get_info()[0]
+    fits = torch.tensor([1.0 if (n_ch > 0 and free >= need) else 0.0], dtype=torch.float64, device=coll_dev)
+    if dist is not None:
+        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+    if float(fits.item()) == 0.0:
+        return {"skipped": "rank %d: shard of %d channels needs %.0f GB, %.0f GB free" % (rank, n_ch, need / 1e9, free / 1e9)}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    cs = synth.generate(n_ch, T, seed=a.seed, first_channel=lo)
+    plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, a.mode, muahuff.WIN_AFTER_CAL, tab, seg_chunks=a.seg_chunks)
+    enc = plan.alloc_encoded()
+    out = torch.empty_like(cs.data)
+    plan.encode(cs.data, out=enc)
+    plan.decode(enc, out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.configs3_steps):
+        plan.encode(cs.data, out=enc)
+        plan.decode(enc, out)
+    barrier()
+    dt = time.perf_counter() - t0
+    acc = torch.tensor([float(plan.window_samples), float(enc.ch_bits.sum().item()), float(enc.seg_words.sum().item())],
+                       dtype=torch.float64, device=coll_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    if dist is not None:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ok = None
+    if a.verify:  # channel blocks, so that the check needs no second copy of the shard
+        ok, c = True, 2 ** h
+        for c0 in range(0, n_ch, 64):
+            c1 = min(n_ch, c0 + 64)
+            vin = cs.data[c0 * T:c1 * T].view(c1 - c0, T)[:, c:]
+            vout = out[c0 * T:c1 * T].view(c1 - c0, T)[:, c:]
+            ok = ok and bool(torch.equal(torch.clamp(vin, max=S - 1), vout))
+        okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
+        if dist is not None:
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item() == 1.0)
+    plan.close()
+    del cs, enc, out
+    torch.cuda.empty_cache()
+    samples, bits, words = (float(v) for v in acc.tolist())
+    dt = float(tmax.item())
+    res = {"workload": "BASELINE configs[3]: synthetic Poisson MUA, %d channels x %.0e bins in all, sharded over %d GPU(s)"
+                       % (a.total_channels, T, world),
+           "scaling": "strong", "total_channels": a.total_channels, "channels_rank0": n_ch, "steps": a.configs3_steps,
+           "ms_per_step": dt / a.configs3_steps * 1e3, "MSamples_s": samples * a.configs3_steps / dt / 1e6,
+           "bits_per_sample": bits / samples, "payload_bytes_total": words * 4.0}
+    if ok is not None:
+        res["verified_roundtrip"] = ok
+    return res
+
+
 # ---- one rank ------------------------------------------------------------------------------------
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -320,10 +399,12 @@ def main(argv=None):
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    devices = None
+    devices, rank_words = None, None
     if dist is not None:
         devices = [None] * world
         dist.all_gather_object(devices, "%s cuda:%d" % (torch.cuda.get_device_name(local), local))
+        rank_words = [None] * world   # words every rank's encoder wrote (sum of seg_words): what the gather must move
+        dist.all_gather_object(rank_words, int(enc.seg_words.sum().item()))
 
     # auxiliary, outside the timed region: mh_measure on the same resident batch with the
     # reference's own window rule [c, c+T/2) -- the only thing the reference itself computes
@@ -361,7 +442,11 @@ def main(argv=None):
             barrier()
             g = time.perf_counter() - g0
             box["v"] = dict(ms=g * 1e3, bytes_total=int(offs[-1]) * 4, payload_device=str(src.device),
+                            words_per_rank=[int(v) for v in np.diff(offs)],
                             GBps_into_root=(int(offs[-1]) - int(offs[1])) * 4 / g / 1e9)
+            if rank == 0 and a.verify:  # the root's copy of its own shard travelled through the same slicing
+                box["v"]["root_shard_intact"] = bool(torch.equal(pay[:int(offs[1])].to(dense.payload.device),
+                                                                 dense.payload[:int(offs[1])]))
             del pay, src, dense
             # the same gather pipelined behind the encoder: 4 channel blocks per rank, block b is on the
             # wire while block b+1 encodes (dist.gather_payload_pipelined); every block has its own buffers
@@ -418,6 +503,18 @@ def main(argv=None):
         vin = cs.data[:C * T].view(C, T)[:, c:]
         vout = out[:C * T].view(C, T)[:, c:]
         ok = bool(torch.equal(torch.clamp(vin, max=S - 1), vout))
+        if dist is not None:  # every rank's shard, not just rank 0's
+            okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = bool(okt.item() == 1.0)
+        del vin, vout
+
+    c3 = None
+    if world > 1 and not a.no_configs3 and rc != RC_GATHER_STUCK:  # (N = 1 runs it last, once the per-S sweep no longer needs the headline's buffers)
+        plan.close()
+        del cs, enc, out, plan
+        torch.cuda.empty_cache()
+        c3 = configs3_block(a, rank, world, dist, coll_dev, tab)
 
     if rank == 0:
         total_samples = samples * world
@@ -440,6 +537,9 @@ def main(argv=None):
         info = muahuff.device_info(local)
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # the PMC passes cannot run inside a timed run: the figure is read from the committed profile of this
+                # same command, not measured by THIS run
+                "traffic_measured": False,
                 # MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79%)"
                 "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0,
                 "traffic_source": traffic_src, "algorithmic_bytes": abytes,
@@ -476,12 +576,15 @@ def main(argv=None):
             line["rccl_ranks"] = dist.get_world_size()
             line["dist_backend"] = a.dist_backend
             line["rank_devices"] = devices
+            line["rank_payload_words"] = rank_words
         if gather:
             line["gather"] = gather
         if ok is not None:
             line["verified_roundtrip"] = ok
         if not a.no_small_shape and world == 1:
             line["small_shape"] = small_shape(S, h, a.mode, a.seg_chunks)
+        if c3 is not None:
+            line["configs3"] = c3
         if not a.no_cpu_baseline and world == 1:
             nch = min(a.cpu_sample_channels, C)
             nbytes = int(cs.ch_off[nch - 1] + cs.ch_len[nch - 1]) + 64
@@ -494,6 +597,11 @@ def main(argv=None):
                                     "all_cores": res.get("all"), "single": res["1"],
                                     "numpy_measure_msamples_s": res["numpy_measure_msamples_s"],
                                     "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
+        if world == 1 and not a.no_configs3:  # last: the headline's buffers make room for the 10 000-channel set
+            plan.close()
+            del cs, enc, out, plan
+            torch.cuda.empty_cache()
+            line["configs3"] = configs3_block(a, rank, world, None, coll_dev, tab)
         print(json.dumps(line), flush=True)
     sys.stdout.flush()
     if rc == RC_GATHER_STUCK:

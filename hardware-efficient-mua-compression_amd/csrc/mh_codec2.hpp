@@ -21,10 +21,13 @@
 namespace mh {
 
 struct TaskArgs {
-    const uint32_t *task_seg0;  // shared-table kernels: first segment of the workgroup task
-    const uint8_t *task_n;      //   segments in the task (1..4), all of one channel
-    const WaveTask *wt;         // per-wave-table kernels: one record per wave task (mh_planner.hpp)
+    const WgTask *wg;           // shared-table kernels: one record per workgroup task (mh_planner.hpp)
+    const WaveTask *wt;         // per-wave-table kernels: one record per wave task
     uint32_t ntask;
+    // shared-table kernels: geometry of a full segment (every segment of a task but its last is one)
+    uint32_t seg_samples;       // samples
+    uint64_t seg_src_stride;    // bytes between the sources of consecutive segments
+    uint64_t slot_full;         // words between their slots
 };
 
 // ------------------------------------------------------------------------------------------
@@ -696,37 +699,59 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // the four waves' staging buffers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t task = blockIdx.x;
-    const uint32_t seg0 = a.t.task_seg0[task];
-    const uint32_t nseg = a.t.task_n[task];
-    const uint32_t ch = a.e.seg_ch[seg0];
+    // ONE scalar load tells the workgroup everything (no task -> segment -> channel -> offsets chain); what the
+    // tables need (the channel's 16 single-symbol entries) is requested next, then -- without waiting -- the
+    // segment's first rows: two memory round trips from launch to the first codeword instead of five.
+    const WgTask t = a.t.wg[task];
+    const uint32_t nseg = t.nseg, ch = t.ch;
     uint2 *lut2 = s_tab;
     uint2 *lut1 = s_tab + 256;
-    {   // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
-        const uint2 *g = a.e.lut + (size_t)ch * kLut;
-        const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
-        if (PK == 2) {  // four-symbol table indexed by the packed byte
-            lut2[packed_index_word<2>(threadIdx.x) & 0xFFu] = quad_entry(threadIdx.x, [&](uint32_t b) { return g[b]; });
-        } else if (threadIdx.x < (1u << (2 * PB))) {
-            const uint2 ea = g[b0], eb = g[b1];
-            uint32_t idx = b0 | (b1 << PB);
-            if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
-            lut2[idx] = make_uint2(ea.x | (eb.x << ea.y), ea.y + eb.y);
-        }
-        if (threadIdx.x < kLut) lut1[threadIdx.x] = g[threadIdx.x];
+    const uint2 *g = a.e.lut + (size_t)ch * kLut;
+    const uint32_t b0 = threadIdx.x & ((1u << PB) - 1u), b1 = (threadIdx.x >> PB) & ((1u << PB) - 1u);
+    uint2 q0, q1, q2, q3;  // the thread's table inputs (unconditional loads from valid addresses)
+    if (PK == 2) {
+        q0 = g[threadIdx.x & 3u], q1 = g[(threadIdx.x >> 2) & 3u], q2 = g[(threadIdx.x >> 4) & 3u], q3 = g[(threadIdx.x >> 6) & 3u];
+    } else {
+        q0 = g[b0], q1 = g[b1];
+        q2 = q3 = make_uint2(0u, 0u);
     }
+    const uint2 q1s = g[threadIdx.x & (kLut - 1)];
+    // the wave's segment by arithmetic; a wave without one (wave >= nseg) keeps valid addresses and n = 0
+    const uint32_t wv = (uint32_t)wave < nseg ? (uint32_t)wave : 0u;
+    const uint32_t n = (uint32_t)wave + 1 < nseg ? a.t.seg_samples : ((uint32_t)wave + 1 == nseg ? t.n_last : 0u);
+    const uint8_t *src = a.e.data + t.src_off + (uint64_t)wv * a.t.seg_src_stride;
+    typename RawPiece<PK>::type v[kWin];
+    {   // first rows: unconditional (a load inside a branch is waited for with vmcnt(0) at the join)
+        const int frow = n >= (uint32_t)kChunk ? 1 : 0;
+        // (a shorter segment will not use them and may end within 16 bytes of the caller's buffer: its lanes all
+        // read the first 16 bytes of the task record instead -- memory that is certainly there)
+        const uint8_t *first = frow ? src : reinterpret_cast<const uint8_t *>(a.t.wg + task);
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+            v[k] = load_row<PK>(first + (size_t)frow * (((uint32_t)k * kLanes + lane) * piece_bytes<PK>()));
+            asm volatile("" ::: "memory");  // keep the rows in issue order
+        }
+    }
+    // pair table: entry for symbols (b0, b1) = code(b0) followed by code(b1)
+    if (PK == 2) {  // four-symbol table indexed by the packed byte
+        const uint32_t l01 = q0.y + q1.y, l012 = l01 + q2.y;
+        lut2[packed_index_word<2>(threadIdx.x) & 0xFFu] =
+            make_uint2(q0.x | (q1.x << q0.y) | (q2.x << l01) | (q3.x << l012), l012 + q3.y);
+    } else if (threadIdx.x < (1u << (2 * PB))) {
+        uint32_t idx = b0 | (b1 << PB);
+        if (PB == 4) idx ^= (idx >> 3) & 0x1Fu;
+        lut2[idx] = make_uint2(q0.x | (q1.x << q0.y), q0.y + q1.y);
+    }
+    if (threadIdx.x < kLut) lut1[threadIdx.x] = q1s;
     __syncthreads();
-    if ((uint32_t)wave >= nseg) return;
+    if (n == 0) return;
     const uint32_t cap = a.e.stage_dw;
     uint32_t *buf = smem + (size_t)wave * enc2_wave_dwords(cap);
-    const uint32_t seg = seg0 + (uint32_t)wave;
-    typename RawPiece<PK>::type v[kWin];
     uint64_t bits;
     // (packed input exists for whole-channel windows only: w0 = 0 and segments start at chunk boundaries)
-    encode_segment<LC, PB, ABL, false, PK>(a.e, seg, ch,
-                                           a.e.data + a.e.ch_off[ch] +
-                                               (a.e.chunk_stride ? ((a.e.w0[ch] + a.e.seg_first[seg]) / kChunk) * a.e.chunk_stride
-                                                                 : stream_bytes<PK>(a.e.w0[ch] + a.e.seg_first[seg])),
-                                           a.e.seg_n[seg], a.e.payload + a.e.seg_off[seg], v, lut2, lut1, buf, cap, lane, bits);
+    encode_segment<LC, PB, ABL, true, PK>(a.e, t.seg0 + (uint32_t)wave, ch, src, n,
+                                          a.e.payload + t.dst_off + (uint64_t)wave * a.t.slot_full, v, lut2, lut1, buf, cap,
+                                          lane, bits);
 }
 
 // Short channels (the reference's real recordings at 50 ms bins are 2e4-7e4 samples per channel,
@@ -761,10 +786,11 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
     // The segment's first rows are requested before the tables are built -- but AFTER the few small loads the
     // tables depend on: the memory counter retires in order, so those are waited for with the rows still in
     // flight.  The row loads are unconditional for the same reason (loads inside a branch cannot be counted,
-    // and every wait after them would drain the queue); a record shorter than a chunk, which will not use
-    // them, re-reads one piece it may read anyway.
+    // and every wait after them would drain the queue).
     const bool full = t.n >= (uint32_t)kChunk;
-    const uint8_t *first = t.n ? src : a.e.data + (t.cal_off & ~(uint64_t)15);
+    // (a record shorter than a chunk will not use the rows and may end within 16 bytes of the caller's buffer:
+    // its lanes all read the first 16 bytes of the record itself -- memory that is certainly there)
+    const uint8_t *first = full ? src : reinterpret_cast<const uint8_t *>(a.t.wt + slot);
     const int frow = full ? 1 : 0;
     auto first_rows = [&]() {
 #pragma unroll
@@ -950,6 +976,9 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
     uint32_t nxt = kReload ? 0u : stage[wi + 2];
     const uint32_t nfp = m >> 4;                   // complete pieces (PARTIAL)
     const uint32_t nrows_any = (m + 1023u) >> 10;  // rows holding any sample (PARTIAL)
+#ifdef MH_TUNING
+    const int dec_abl = __builtin_amdgcn_readfirstlane(d_dec_abl);  // once per chunk: the row stores below may alias it
+#endif
     auto row = [&](int k) {
         const uint32_t piece = (uint32_t)k * kLanes + lane;
         if (PARTIAL && piece >= nfp) {
@@ -1029,8 +1058,8 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
             o[d] = w;
         }
 #ifdef MH_TUNING  // timing-only ablation (tools/ablate_decode.py): 1 = every row of a chunk lands on its first KiB
-        const uint32_t krow = d_dec_abl == 1 ? 0u : (uint32_t)k;  // (1/16 of the DRAM writes), 2 = no row stores
-        if (d_dec_abl == 2) {
+        const uint32_t krow = dec_abl == 1 ? 0u : (uint32_t)k;  // (1/16 of the DRAM writes), 2 = no row stores
+        if (dec_abl == 2) {
             if ((o.x ^ o.y) == 0x12345678u && o.z == 77u) out[0] = 1;
             return;
         }
@@ -1038,7 +1067,7 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
         const uint32_t krow = (uint32_t)k;
 #endif
 #ifdef MH_TUNING
-        if (d_dec_abl == 3) {  // plain instead of non-temporal row stores
+        if (dec_abl == 3) {  // plain instead of non-temporal row stores
             *reinterpret_cast<u32x4_u *>(out + (krow * kLanes + lane) * MH_PIECE) = o;
             return;
         }
@@ -1358,9 +1387,12 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t task = blockIdx.x;
-    const uint32_t seg0 = a.t.task_seg0[task];
-    const uint32_t nseg = a.t.task_n[task];
-    const uint32_t ch = a.d.seg_ch[seg0];
+    // one record instead of the task -> segment -> channel chain; the segment's own directory entries are read
+    // AFTER the table build on purpose: requesting them up front (and computing the slot by arithmetic) made this
+    // kernel 3-7 % slower at S = 3..5 in three same-box alternations (profiles/r03_wgtask_ab.txt) -- the
+    // encoder, which gains nothing either way, takes everything from the record
+    const WgTask t = a.t.wg[task];
+    const uint32_t seg0 = t.seg0, nseg = t.nseg, ch = t.ch;
     const uint32_t W = a.W;
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
     uint32_t *tab = smem;

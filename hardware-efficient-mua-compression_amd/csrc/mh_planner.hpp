@@ -88,6 +88,21 @@ struct WaveTask {
     uint32_t flags;     // bit 0: first record of the channel (publishes peak / encoder / skipped); bit 1: skipped
 };
 
+// One workgroup task of the shared-table kernels in ONE 32-byte record (one scalar load): up to 4 consecutive
+// segments of one channel.  All but the last segment of a channel are full (seg_chunks chunks), so a wave finds
+// its segment by arithmetic: source = src_off + wave * seg_src_stride, slot = dst_off + wave * slot_full,
+// samples = wave + 1 < nseg ? seg_samples : n_last.  It replaces the task -> segment -> channel -> offsets chain
+// of dependent loads from directories that every workgroup reads exactly once (each link an HBM miss under a
+// streaming load: tools/occ_probe.hip measures ~0.02-0.03 ms of the 1024 x 1e7 encode per link).
+struct WgTask {
+    uint64_t src_off;  // bytes from the data pointer to the first segment's first sample
+    uint64_t dst_off;  // the first segment's slot, words from the payload pointer
+    uint32_t n_last;   // samples of the task's last segment (the others hold seg_chunks whole chunks)
+    uint32_t ch;       // channel
+    uint32_t seg0;     // directory entry of the first segment
+    uint32_t nseg;     // segments (1..4)
+};
+
 struct PlanHost {
     mh_plan_info_t info{};
     uint32_t input_bits = 8;  // 8: one byte per sample; 4 / 2: packed pieces (mh_deinterleave_packed), whole-channel windows only
@@ -102,6 +117,9 @@ struct PlanHost {
     // workgroup tasks of the shared-table kernels: <= 4 consecutive segments of one channel
     std::vector<uint32_t> task_seg0;
     std::vector<uint8_t> task_n;
+    std::vector<WgTask> wg_tasks;   // the same tasks as self-contained records (what the kernels read)
+    uint64_t seg_src_stride = 0;    // bytes between the sources of consecutive full segments of a channel
+    uint64_t slot_full = 0;         // slot words of a full segment
     // wave tasks of the per-wave-table kernels: every segment once, longest first
     std::vector<WaveTask> wave_tasks;
     bool use_wave_tasks = false;
@@ -208,6 +226,14 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
     }
     const uint64_t seg_samples = (uint64_t)I.seg_chunks * MH_CHUNK;
     uint64_t slot = 0, padded_waves = 0;
+    // byte offset of window sample `first` (packed input: a multiple of 16) from the channel's first byte
+    auto src_bytes = [&](uint64_t first) {
+        return p.input_bits == 8 ? first
+               : p.chunk_stride  ? (first / MH_CHUNK) * p.chunk_stride
+                                 : (first >> 4) * (p.input_bits == 4 ? 8u : 4u);
+    };
+    p.seg_src_stride = src_bytes(seg_samples);
+    p.slot_full = slot_words(seg_samples, I.maxlen);
     for (uint32_t c = 0; c < C; ++c) {
         const uint64_t n = p.w1[c] - p.w0[c];
         const size_t seg_begin = p.seg_ch.size();
@@ -220,8 +246,17 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
             slot += slot_words(m, I.maxlen);
         }
         for (size_t s0 = seg_begin; s0 < p.seg_ch.size(); s0 += 4) {
+            const uint32_t cnt = (uint32_t)(p.seg_ch.size() - s0 < 4 ? p.seg_ch.size() - s0 : 4);
             p.task_seg0.push_back((uint32_t)s0);
-            p.task_n.push_back((uint8_t)(p.seg_ch.size() - s0 < 4 ? p.seg_ch.size() - s0 : 4));
+            p.task_n.push_back((uint8_t)cnt);
+            WgTask t{};
+            t.src_off = ch_off[c] + src_bytes(p.w0[c] + p.seg_first[s0]);
+            t.dst_off = p.seg_off[s0];
+            t.n_last = (uint32_t)p.seg_n[s0 + cnt - 1];
+            t.ch = c;
+            t.seg0 = (uint32_t)s0;
+            t.nseg = cnt;
+            p.wg_tasks.push_back(t);
             padded_waves += 4;
         }
         for (uint64_t first = 0; first < n; first += kHistTileBytes) {
@@ -270,9 +305,7 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
             const uint32_t c = p.seg_ch[s];
             WaveTask t = record(c);
             const uint64_t first = p.w0[c] + p.seg_first[s];  // packed input: a multiple of 16 (whole-channel windows)
-            t.src_off = ch_off[c] + (p.input_bits == 8 ? first
-                                     : p.chunk_stride ? (first / MH_CHUNK) * p.chunk_stride
-                                                      : (first >> 4) * (p.input_bits == 4 ? 8u : 4u));
+            t.src_off = ch_off[c] + src_bytes(first);
             t.dst_off = p.seg_off[s];
             t.n = (uint32_t)p.seg_n[s];
             t.seg = s;

@@ -91,8 +91,7 @@ struct mh_plan {
     uint2 *d_lut = nullptr;
     // shared-table kernels: workgroup tasks (first segment, count); per-wave-table kernels: the
     // segment of every wave task
-    uint32_t *d_task_seg0 = nullptr;
-    uint8_t *d_task_n = nullptr;
+    mh::WgTask *d_wg_tasks = nullptr;
     mh::WaveTask *d_wave_tasks = nullptr;
     uint64_t *d_scan = nullptr;  // block sums of mh_compact's segment scan
     // calibration windows above kCalDirect samples: tiles for the window-histogram kernel
@@ -237,7 +236,11 @@ static int launch_encode2w(const mh::Enc2Args &a, hipStream_t st)
     return MH_OK;
 }
 
-constexpr size_t kDecK4LdsFloor = 41 * 1024;  // 3 workgroups per CU (see launch_decode2)
+#ifndef MH_DEC_K4_LDS_FLOOR
+#define MH_DEC_K4_LDS_FLOOR (41 * 1024)
+#endif
+constexpr size_t kDecK4LdsFloor = MH_DEC_K4_LDS_FLOOR;  // 3 workgroups per CU (see launch_decode2)
+
 
 template <int K, int M, int NR, int RL, bool HY>
 static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st)
@@ -450,7 +453,7 @@ int mh_plan_destroy(mh_plan *p)
                     p->d_tile_done, p->d_codes,
                     p->d_seg_ch, p->d_seg_first, p->d_seg_n, p->d_seg_off, p->d_tile_ch,
                     p->d_tile_n, p->d_tile_start, p->d_hist, p->d_peak, p->d_enc,
-                    p->d_lut, p->d_task_seg0, p->d_task_n, p->d_wave_tasks, p->d_scan,
+                    p->d_lut, p->d_wg_tasks, p->d_wave_tasks, p->d_scan,
                     p->d_cal_tile_ch, p->d_cal_tile_n, p->d_cal_tile_start, p->d_calhist, p->d_err, p->d_acc};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -479,7 +482,7 @@ static int plan_upload(mh_plan *p)
         (rc = upload(&p->d_tile_start, H.tile_start)) ||
         (rc = alloc(&p->d_hist, (size_t)C * mh::kHistStride)) || (rc = alloc(&p->d_peak, C)) ||
         (rc = alloc(&p->d_enc, C)) || (rc = alloc(&p->d_lut, (size_t)C * mh::kLut)) ||
-        (rc = upload(&p->d_task_seg0, H.task_seg0)) || (rc = upload(&p->d_task_n, H.task_n)) ||
+        (rc = upload(&p->d_wg_tasks, H.wg_tasks)) ||
         (H.use_wave_tasks && (rc = upload(&p->d_wave_tasks, H.wave_tasks))) ||
         (rc = alloc(&p->d_scan, H.seg_ch.size() / mh::kScanBlock + 2)) || (rc = upload(&p->d_err, std::vector<uint32_t>(1, 0u))) ||
         (H.use_wave_tasks && (rc = upload(&p->d_acc, std::vector<unsigned long long>(C, 0ull)))) ||
@@ -666,17 +669,16 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
 
 static mh::TaskArgs task_args(const mh_plan *p)
 {
-    mh::TaskArgs t;
+    mh::TaskArgs t{};
     if (p->h.use_wave_tasks) {  // one wave per segment, longest first
-        t.task_seg0 = nullptr;
-        t.task_n = nullptr;
         t.wt = p->d_wave_tasks;
         t.ntask = (uint32_t)p->h.wave_tasks.size();
     } else {                    // one workgroup per <= 4 consecutive segments of a channel
-        t.task_seg0 = p->d_task_seg0;
-        t.task_n = p->d_task_n;
-        t.wt = nullptr;
-        t.ntask = (uint32_t)p->h.task_seg0.size();
+        t.wg = p->d_wg_tasks;
+        t.ntask = (uint32_t)p->h.wg_tasks.size();
+        t.seg_samples = p->h.info.seg_chunks * MH_CHUNK;
+        t.seg_src_stride = p->h.seg_src_stride;
+        t.slot_full = p->h.slot_full;
     }
     return t;
 }

@@ -70,6 +70,20 @@ int main()
             covered += p.task_n[t];
         }
         CHECK(covered == n);
+        // the same tasks as self-contained records: what a wave derives by arithmetic equals the directory
+        CHECK(p.wg_tasks.size() == p.task_seg0.size());
+        const uint64_t seg_samples = (uint64_t)p.info.seg_chunks * MH_CHUNK;
+        CHECK(p.seg_src_stride == seg_samples && p.slot_full == mh::slot_words(seg_samples, maxlen));
+        for (size_t t = 0; t < p.wg_tasks.size(); ++t) {
+            const mh::WgTask &w = p.wg_tasks[t];
+            CHECK(w.seg0 == p.task_seg0[t] && w.nseg == p.task_n[t] && w.ch == p.seg_ch[w.seg0]);
+            for (uint32_t k = 0; k < w.nseg; ++k) {
+                const size_t sg = (size_t)w.seg0 + k;
+                CHECK(w.src_off + k * p.seg_src_stride == off[w.ch] + p.w0[w.ch] + p.seg_first[sg]);
+                CHECK(w.dst_off + k * p.slot_full == p.seg_off[sg]);
+                CHECK((k + 1 < w.nseg ? seg_samples : (uint64_t)w.n_last) == p.seg_n[sg]);
+            }
+        }
         if (p.use_wave_tasks) {  // every segment once, longest first, then one record per channel without segments
             std::vector<uint8_t> seen(n, 0);
             std::vector<uint32_t> per_ch(C, 0), first_ch(C, 0);

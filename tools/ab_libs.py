@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of two builds of libmuahuff.so: encode / decode of the roofline set (1024 channels x
 1e7 bins) per S and of the short-channel set, each library in its own child process, alternating.
+env: SS=3,5,8,10  REPS=2  RATES=lo,hi  H=6 (calibration bits: the window starts at sample 2^H)  SMALL_ONLY=1  BIG_ONLY=1
 usage: ab_libs.py A.so B.so ...      (children: ab_libs.py --one X.so)"""
 import os
 import subprocess
@@ -32,12 +33,14 @@ def one(path):
     shapes = ((1024, 10_000_000, 30), (2400, 72_000, 50), (96, 72_000, 50), (10_000, 20_000, 50), (96, 3_600_000, 50))
     if os.environ.get("SMALL_ONLY") == "1":
         shapes = shapes[1:]
+    if os.environ.get("BIG_ONLY") == "1":
+        shapes = shapes[:1]
     for C, T, n in shapes:
         lo, hi = [float(v) for v in os.environ.get("RATES", "0.2,3.0").split(",")]  # counts per bin, log-uniform over channels
         cs = synth.generate(C, T, seed=5, lo=lo, hi=hi)
         out = torch.empty_like(cs.data)
         for S in (Ss if T > 1_000_000 or os.environ.get("SMALL_ONLY") == "1" else Ss[:2]):
-            plan = codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, muahuff.WIN_AFTER_CAL, sclv.table(S))
+            plan = codec.Plan(cs.ch_off, cs.ch_len, S, int(os.environ.get("H", "6")), 1, muahuff.WIN_AFTER_CAL, sclv.table(S))
             enc = plan.alloc_encoded()
             e = timed(lambda: plan.encode(cs.data, out=enc), n)
             d = timed(lambda: plan.decode(enc, out), n)

@@ -33,11 +33,27 @@ __global__ __launch_bounds__(256) void k_dec_mix(const uint8_t* __restrict__ src
 }
 
 // encoder mix: read the 16 KiB chunks (8 rows in flight, nt loads), write `wout` bytes per chunk (nt stores)
-__global__ __launch_bounds__(256) void k_enc_mix(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t chunks, uint32_t wout, size_t nseg, size_t slot)
+__global__ __launch_bounds__(256) void k_enc_mix(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t chunks, uint32_t wout, size_t nseg, size_t slot,
+                                                 const uint32_t* __restrict__ tbl = nullptr, int chain = 0, int sync = 0)
 {
     extern __shared__ uint32_t pad[];
     const int lane = threadIdx.x & 63;
-    const size_t seg = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    size_t seg = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // fake prologue: `chain` dependent loads (a directory walk: task -> segment -> channel -> table), optionally a
+    // workgroup barrier behind them, before the first row is requested
+    if (chain > 0) {
+        uint32_t j = (uint32_t)(blockIdx.x & 1023u);
+        for (int i = 0; i < chain; ++i) j = tbl[j] + (uint32_t)(blockIdx.x & 1023u);
+        if (sync) __syncthreads();
+        seg += j >> 31;  // (tbl holds zeros: j == blockIdx & 1023 < 2^31)
+    } else if (chain < 0) {
+        // the same walk through directories that are read ONCE (as the codec's are): every workgroup's loads hit
+        // lines nobody has touched -- 32 bytes apart per workgroup, a different 8 MiB array per step
+        uint32_t j = blockIdx.x * 8u;
+        for (int i = 0; i < -chain; ++i) j = tbl[(size_t)i * (2u << 20) + j] + blockIdx.x * 8u;
+        if (sync) __syncthreads();
+        seg += j >> 31;
+    }
     if (seg >= nseg) return;
     const uint8_t* p = src + seg * (size_t)chunks * 16384;
     uint8_t* o = dst + seg * slot;
@@ -88,6 +104,34 @@ int main()
         float e = timeit([&]{ hipLaunchKernelGGL(k_enc_mix, dim3((nseg+3)/4), dim3(256), lds, 0, big, small_, chunks, 2944u, nseg, slot); });
         printf("%d workgroups/CU : decoder mix nt %.3f ms  plain %.3f ms | pure write nt %.3f  plain %.3f | encoder mix %.3f ms\n", wg, a, b, c, d, e);
         fflush(stdout);
+    }
+    {   // the encoder mix behind a prologue of dependent loads, 4 workgroups per CU
+        uint32_t* tbl; CK(hipMalloc(&tbl, 4096 * 4)); CK(hipMemset(tbl, 0, 4096 * 4));
+        const size_t lds = (size_t)160 * 1024 / 4 - 1024;
+        CK(hipFuncSetAttribute((const void*)k_enc_mix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int chain : {0, 1, 2, 3, 5, 8})
+            for (int sync : {0, 1}) {
+                float e = timeit([&]{ hipLaunchKernelGGL(k_enc_mix, dim3((nseg+3)/4), dim3(256), lds, 0, big, small_, chunks, 2944u, nseg, slot, (const uint32_t*)tbl, chain, sync); });
+                float r = timeit([&]{ hipLaunchKernelGGL(k_enc_mix, dim3((nseg+3)/4), dim3(256), lds, 0, big, small_, chunks, 0u, nseg, slot, (const uint32_t*)tbl, chain, sync); });
+                printf("encoder mix, prologue of %d dependent loads%s : %.3f ms   (reads only: %.3f ms)\n", chain, sync ? " + barrier" : "", e, r);
+                fflush(stdout);
+            }
+        {
+            uint32_t* dir; CK(hipMalloc(&dir, (size_t)8 * (8u << 20))); CK(hipMemset(dir, 0, (size_t)8 * (8u << 20)));
+            for (int chain : {-1, -2, -3, -5, -8})
+                for (int sync : {0, 1}) {
+                    float e = timeit([&]{ hipLaunchKernelGGL(k_enc_mix, dim3((nseg+3)/4), dim3(256), lds, 0, big, small_, chunks, 2944u, nseg, slot, (const uint32_t*)dir, chain, sync); });
+                    float r = timeit([&]{ hipLaunchKernelGGL(k_enc_mix, dim3((nseg+3)/4), dim3(256), lds, 0, big, small_, chunks, 0u, nseg, slot, (const uint32_t*)dir, chain, sync); });
+                    printf("encoder mix, prologue of %d dependent loads from read-once directories%s : %.3f ms   (reads only: %.3f ms)\n", -chain, sync ? " + barrier" : "", e, r);
+                    fflush(stdout);
+                }
+        }
+        // rows that start 64 bytes into a 128-byte line (the window of the chosen system starts at sample 2^6)
+        for (size_t shift : {(size_t)0, (size_t)64, (size_t)16}) {
+            float e = timeit([&]{ hipLaunchKernelGGL(k_enc_mix, dim3((nseg+3)/4 - 1), dim3(256), lds, 0, big + shift, small_, chunks, 2944u, nseg - 4, slot, (const uint32_t*)tbl, 0, 0); });
+            float d = timeit([&]{ hipLaunchKernelGGL(k_dec_mix<1>, dim3((nseg+3)/4 - 1), dim3(256), (size_t)41984, 0, small_, big + shift, chunks, 2944u, nseg - 4, slot); });
+            printf("rows shifted by %zu bytes : encoder mix %.3f ms, decoder mix (3 workgroups/CU) %.3f ms\n", shift, e, d);
+        }
     }
     return 0;
 }
