@@ -188,12 +188,19 @@ __device__ __forceinline__ void pair_entries(uint32_t x, const uint2 *lut2, uint
 // as MACROS because two functions need the same statements -- encode_full_chunk's unrolled row loop and
 // encode_row for partial chunks -- and routing the hot loop through a function cost the S = 10 kernel 6 %:
 // one source text, two expansions.  The expansion site provides LC, PB, ABL, lut2, acc, nb, sp, st, cap.
-#define MH_FLUSH()                                                                          \
-    if (nb >= 32) {                                                                         \
-        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[sp * 16] = (uint32_t)acc;    \
-        acc >>= 32;                                                                         \
-        nb -= 32;                                                                           \
-        ++sp;                                                                               \
+__host__ __device__ constexpr int stage_ne(int LC) { return LC == 0 ? 4 : 8; }  // cap / 4 for the largest cap of the class
+
+// Where a lane keeps its j-th spilled dword: staging ROW (j % NE) * 4 + j / NE of its column (NE = dwords one lane of
+// the merge gathers per group, stage_ne(LC)).  The merge's lane (sub-stream s, quarter q) reads rows r * 4 + q,
+// r = 0 .. NE-1 -- 64 consecutive LDS words per instruction, no bank conflict -- and with this permutation those are
+// the CONSECUTIVE dwords q * NE + r of the sub-stream, so each output word is a funnel shift of two registers.
+#define MH_STAGE_AT(j) ((((j) & (uint32_t)(MH_NE_ - 1)) << 2 | ((j) >> (MH_NE_ == 4 ? 2 : 3))) * 16)
+#define MH_FLUSH()                                                                                  \
+    if (nb >= 32) {                                                                                 \
+        if ((ABL < 3 || ABL >= 5) && (LC <= 1 || sp < cap)) st[MH_STAGE_AT(sp)] = (uint32_t)acc;    \
+        acc >>= 32;                                                                                 \
+        nb -= 32;                                                                                   \
+        ++sp;                                                                                       \
     }
 
 // Short codes (LC 0: max length 2, LC 1: max length 4): the 16 codewords of a piece.  Everything that fits
@@ -325,8 +332,15 @@ __device__ __forceinline__ uint32_t *stage_lane_base(uint32_t *buf, uint32_t cap
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
     __builtin_amdgcn_wave_barrier()
 
-// NE >= cap/4: staged dwords one lane gathers per group
-template <int NE, int ABL>
+// NE >= cap/4: staged dwords one lane gathers per group.
+// FULL (a chunk of 16384 samples: every sub-stream has >= 256 bits, so a payload word is shared by at most TWO
+// neighbouring sub-streams): a sub-stream is contiguous at bit offset P, so word P/32 + j of the image is the funnel
+// shift (v[j] << s) | (v[j-1] >> (32 - s)), s = P % 32, of two CONSECUTIVE staged dwords -- which the gather holds in
+// neighbouring registers (MH_STAGE_AT), the one at a quarter's start coming from the lane 16 below.  Interior words are
+// written with plain ds_write; only a sub-stream's first and last word, which it may share with its neighbours, are
+// OR-ed into words zeroed beforehand: 2 LDS atomics per sub-stream instead of up to 2 per staged dword (and no
+// zero-fill of the image).  Partial chunks (sub-streams of any length, several to a word) keep the OR for every dword.
+template <int NE, int ABL, bool FULL>
 __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uint32_t tot, uint32_t sp,
                                                 uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
                                                 uint32_t &words, uint32_t &bits)
@@ -348,31 +362,56 @@ __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uin
     }
     const uint32_t *R = buf + 96;
     const int sl = lane & 15, jq = lane >> 4;
-    uint32_t zeroed = 0;  // payload words [0, zeroed) are initialised
+    uint32_t zeroed = 0;  // !FULL: payload words [0, zeroed) are initialised
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
         const int src = g * 16 + sl;
         const uint32_t sp_s = __shfl(sp, src, 64), P_s = __shfl(P, src, 64);
         const uint32_t *sg = R + (uint32_t)g * 16 * cap;
-        uint32_t vals[NE];
+        uint32_t vals[NE];  // staged dwords jq * NE + r of sub-stream `src` (0 past its end)
 #pragma unroll
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t jj = (uint32_t)(r * 4 + jq);
-            vals[r] = jj < sp_s ? sg[jj * 16 + sl] : 0u;
-        }
+        for (int r = 0; r < NE; ++r) vals[r] = (uint32_t)(jq * NE + r) < sp_s ? sg[(uint32_t)(r * 4 + jq) * 16 + sl] : 0u;
         MH_WAVE_SYNC();
-        const uint32_t w_end = (__shfl(incl, g * 16 + 15, 64) + 31) >> 5;
-        for (uint32_t i = zeroed + lane; i < w_end; i += 64) pay[i] = 0;
-        zeroed = w_end;
-        MH_WAVE_SYNC();
+        if (FULL) {
+            const uint32_t tot_s = __shfl(tot, src, 64);
+            const uint32_t s = P_s & 31u, base = P_s >> 5;
+            const uint32_t nword = (s + tot_s + 31) >> 5;          // image words the sub-stream touches (>= 8)
+            const bool tail_shared = ((s + tot_s) & 31u) != 0;     // its last word also holds the next sub-stream's head
+            // zero the words this group will OR into: every sub-stream's shared last word (its first word is the
+            // previous sub-stream's last: zeroed by the same instruction, or by the previous group's)
+            if (jq == 0 && tail_shared) pay[base + nword - 1] = 0;
+            uint32_t prev = __shfl(vals[NE - 1], lane - 16, 64);   // dword jq * NE - 1 sits one quarter down
+            if (jq == 0) prev = 0;
+            MH_WAVE_SYNC();
 #pragma unroll
-        for (int r = 0; r < NE; ++r) {
-            const uint32_t jj = (uint32_t)(r * 4 + jq);
-            if (jj < sp_s) {
-                const uint32_t pos = P_s + 32 * jj;
-                const uint64_t sh = (uint64_t)vals[r] << (pos & 31);
-                atomicOr(&pay[pos >> 5], (uint32_t)sh);
-                if ((uint32_t)(sh >> 32)) atomicOr(&pay[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+            for (int r = 0; r <= NE; ++r) {
+                // (r == NE: word 4 * NE, which exists only when the sub-stream fills the whole staging and does not
+                // start on a word boundary -- the top quarter emits it from its last register)
+                if (r == NE && jq != 3) break;
+                const uint32_t j = (uint32_t)(jq * NE + r);
+                const uint32_t cur = r < NE ? vals[r < NE ? r : 0] : 0u, lo = r ? vals[r - 1] : prev;
+                const uint32_t w = s ? __builtin_amdgcn_alignbit(cur, lo, 32u - s) : cur;
+                if (j < nword) {
+                    if ((j == 0 && s != 0) || (j + 1 == nword && tail_shared))
+                        atomicOr(&pay[base + j], w);
+                    else
+                        pay[base + j] = w;
+                }
+            }
+        } else {
+            const uint32_t w_end = (__shfl(incl, g * 16 + 15, 64) + 31) >> 5;
+            for (uint32_t i = zeroed + lane; i < w_end; i += 64) pay[i] = 0;
+            zeroed = w_end;
+            MH_WAVE_SYNC();
+#pragma unroll
+            for (int r = 0; r < NE; ++r) {
+                const uint32_t jj = (uint32_t)(jq * NE + r);
+                if (jj < sp_s) {
+                    const uint32_t pos = P_s + 32 * jj;
+                    const uint64_t sh = (uint64_t)vals[r] << (pos & 31);
+                    atomicOr(&pay[pos >> 5], (uint32_t)sh);
+                    if ((uint32_t)(sh >> 32)) atomicOr(&pay[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+                }
             }
         }
         MH_WAVE_SYNC();
@@ -452,6 +491,7 @@ template <int LC, int PB, int ABL>
 __device__ __forceinline__ void encode_row(u32x4 x, const uint2 *lut2, uint64_t &acc, uint32_t &nb, uint32_t &sp,
                                            uint32_t *st, uint32_t cap)
 {
+    constexpr int MH_NE_ = stage_ne(LC);
     MH_ENCODE_ROW(x)
 }
 
@@ -462,6 +502,7 @@ template <int LC, int PK, int ABL>
 __device__ __forceinline__ void encode_row_packed(typename RawPiece<PK>::type r, const uint2 *lut2, uint64_t &acc,
                                                   uint32_t &nb, uint32_t &sp, uint32_t *st, uint32_t cap)
 {
+    constexpr int MH_NE_ = stage_ne(LC);
     if constexpr (PK == 2) {
         // 16 codewords in four lookups; LC 0 (max length 2): they always fit one dword, LC 1 (<= 4): 8 do
         const uint32_t y = packed_index_word<2>(r);
@@ -516,6 +557,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
                                                   uint32_t *buf, uint32_t cap, uint32_t *__restrict__ &dst,
                                                   uint32_t &pend, int lane, uint32_t &words, uint32_t &bits)
 {
+    constexpr int MH_NE_ = stage_ne(LC);
     uint64_t acc = 0;
     uint32_t nb = 0, sp = 0;
     uint32_t *st = stage_lane_base(buf, cap, lane);
@@ -549,7 +591,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     }
     const uint32_t tot = sp * 32 + nb;
     if (nb > 0) {
-        if (LC <= 1 || sp < cap) st[sp * 16] = (uint32_t)acc;
+        if (LC <= 1 || sp < cap) st[MH_STAGE_AT(sp)] = (uint32_t)acc;
         ++sp;
     }
     MH_WAVE_SYNC();
@@ -557,7 +599,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
         overflow_chunk<false, PK>(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
         return;
     }
-    merge_and_flush<(LC == 0 ? 4 : 8), ABL>(buf, cap, tot, sp, dst, pend, lane, words, bits);
+    merge_and_flush<stage_ne(LC), ABL, true>(buf, cap, tot, sp, dst, pend, lane, words, bits);
 }
 
 // Last, partial chunk of a channel (m < 16384 samples).  Its full pieces (16 samples) take the same
@@ -570,7 +612,7 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
                                                    const uint2 *lut1, uint32_t *buf, uint32_t cap,
                                                    uint32_t *__restrict__ dst0, uint32_t pend, int lane)
 {
-    constexpr int NE = LC == 0 ? 4 : 8;
+    constexpr int NE = stage_ne(LC), MH_NE_ = NE;
     uint32_t *__restrict__ dst = dst0;
     uint32_t words, bits;
     uint64_t acc = 0;
@@ -608,7 +650,7 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
             acc |= (uint64_t)e.x << nb;
             nb += e.y;
             if (nb >= 32) {
-                if (LC <= 1 || sp < cap) st[sp * 16] = (uint32_t)acc;
+                if (LC <= 1 || sp < cap) st[MH_STAGE_AT(sp)] = (uint32_t)acc;
                 acc >>= 32;
                 nb -= 32;
                 ++sp;
@@ -617,14 +659,14 @@ __device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ s
     }
     const uint32_t tot = sp * 32 + nb;
     if (nb > 0) {
-        if (LC <= 1 || sp < cap) st[sp * 16] = (uint32_t)acc;
+        if (LC <= 1 || sp < cap) st[MH_STAGE_AT(sp)] = (uint32_t)acc;
         ++sp;
     }
     MH_WAVE_SYNC();
     if (LC >= 2 && __any(sp > cap))
         overflow_chunk<true, PK>(src, m, lut1, buf, dst, pend, lane, words, bits);
     else
-        merge_and_flush<NE, 0>(buf, cap, tot, sp, dst, pend, lane, words, bits);
+        merge_and_flush<NE, 0, false>(buf, cap, tot, sp, dst, pend, lane, words, bits);
     return make_uint4(words, bits, pend, (uint32_t)(dst - dst0));
 }
 
@@ -644,11 +686,15 @@ __device__ __forceinline__ void load_first_rows(typename RawPiece<PK>::type (&v)
 // src = first sample, n = samples, out = the segment's slot.  PRE: the caller has already issued
 // load_first_rows into v (when n >= one chunk) -- the per-wave-table kernel does so before it builds
 // its tables, so that the rows are in flight while the table entries are computed.
-template <int LC, int PB, int ABL, bool PRE, int PK>
+// PUBLISH: the wave stores the segment's word count and adds its bits to the channel's total itself (wave tasks);
+// otherwise the caller does (the shared-table kernel publishes a whole task at once: one 32-byte store and one
+// atomic per workgroup instead of four scattered 8-byte stores and four atomics -- 313 000 of each per launch on
+// the 1024 x 1e7 set cost 0.06 ms, tools/ablate_encode.py level 15).
+template <int LC, int PB, int ABL, bool PRE, int PK, bool PUBLISH = true>
 __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, uint32_t ch, const uint8_t *src, uint64_t n,
                                                uint32_t *__restrict__ out, typename RawPiece<PK>::type (&v)[kWin], const uint2 *lut2,
                                                const uint2 *lut1, uint32_t *buf, uint32_t cap, int lane,
-                                               uint64_t &seg_bits)
+                                               uint64_t &seg_bits, uint64_t *seg_words_out = nullptr)
 {
     uint32_t pend = 0;  // words waiting in LDS behind `out` (the next unflushed word)
     const uint32_t nfull = (uint32_t)(n / kChunk);
@@ -677,11 +723,13 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
         pend = r.z;
         out += r.w;
     }
-    if ((ABL < 1 || ABL >= 5) && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
-    if (lane == 0) {
+    // (tuning builds: ABL 14 = everything but this partial-block store, 15 = also without seg_words / ch_bits)
+    if ((ABL < 1 || ABL >= 5) && ABL != 14 && ABL != 15 && (uint32_t)lane < pend) out[lane] = buf[lane];  // segment tail (partial block)
+    if (PUBLISH && lane == 0 && ABL != 15) {
         e.seg_words[seg] = words;
         if (!PRE || e.cal_mode == 0) atomicAdd(&e.ch_bits[ch], (unsigned long long)bits);  // zeroed by k_calibrate
     }
+    if (!PUBLISH) *seg_words_out = words;
     seg_bits = bits;
 }
 
@@ -696,6 +744,7 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     // the workgroup's tables are STATIC shared memory: their addresses are compile-time constants that go into
     // the offset field of the ds_read, so a pre-scaled table index is the instruction's address operand as it is
     __shared__ __attribute__((aligned(16))) uint2 s_tab[kEncSharedDw / 2];
+    __shared__ uint64_t s_pub[8];  // what the four waves report: words[4], bits[4]
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];  // the four waves' staging buffers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t task = blockIdx.x;
@@ -744,14 +793,24 @@ __global__ __launch_bounds__(256, 4) void k_encode2(Enc2Args a)
     }
     if (threadIdx.x < kLut) lut1[threadIdx.x] = q1s;
     __syncthreads();
-    if (n == 0) return;
     const uint32_t cap = a.e.stage_dw;
     uint32_t *buf = smem + (size_t)wave * enc2_wave_dwords(cap);
-    uint64_t bits;
+    uint64_t bits = 0, words = 0;
     // (packed input exists for whole-channel windows only: w0 = 0 and segments start at chunk boundaries)
-    encode_segment<LC, PB, ABL, true, PK>(a.e, t.seg0 + (uint32_t)wave, ch, src, n,
-                                          a.e.payload + t.dst_off + (uint64_t)wave * a.t.slot_full, v, lut2, lut1, buf, cap,
-                                          lane, bits);
+    if (n)
+        encode_segment<LC, PB, ABL, true, PK, false>(a.e, t.seg0 + (uint32_t)wave, ch, src, n,
+                                                     a.e.payload + t.dst_off + (uint64_t)wave * a.t.slot_full, v, lut2, lut1, buf,
+                                                     cap, lane, bits, &words);
+    // the task's results leave together: word counts of its <= 4 segments in one store, ONE atomic for the channel
+    if (lane == 0) {
+        s_pub[wave] = words;
+        s_pub[4 + wave] = bits;
+    }
+    __syncthreads();
+    if (ABL == 15) return;
+    if (threadIdx.x < nseg) a.e.seg_words[t.seg0 + threadIdx.x] = s_pub[threadIdx.x];
+    if (threadIdx.x == 0)
+        atomicAdd(&a.e.ch_bits[ch], (unsigned long long)(s_pub[4] + s_pub[5] + s_pub[6] + s_pub[7]));  // zeroed by k_calibrate / k_lut_preset
 }
 
 // Short channels (the reference's real recordings at 50 ms bins are 2e4-7e4 samples per channel,

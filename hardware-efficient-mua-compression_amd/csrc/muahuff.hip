@@ -270,10 +270,12 @@ static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st
     return MH_OK;
 }
 
-// lane-private LDS staging of the encoder: worst case 8*maxlen dwords per lane, capped at 32
-// (= 4 bits per sample averaged over a 256-sample sub-stream; a clipped spike-count channel at
-// S <= 10 stays well below that).  Chunks that outgrow it take the two-pass global slow path.
-static inline uint32_t enc_stage_dw(uint32_t maxlen) { return 8 * maxlen < 32 ? 8 * maxlen : 32; }
+// lane-private LDS staging of the encoder: 16 dwords per lane for codes of at most 2 bits (the worst case of a
+// 256-sample sub-stream), else 32 (= 4 bits per sample on average: the worst case up to 4-bit codes; a clipped
+// spike-count channel at S <= 10 stays well below that, and chunks that outgrow it take the two-pass global slow
+// path).  Always 4 * stage_ne(LC) rows: the staging rows are permuted so that the merge gathers consecutive dwords
+// (MH_STAGE_AT), which needs the row count the kernel class was compiled for.
+static inline uint32_t enc_stage_dw(uint32_t maxlen) { return maxlen <= 2 ? 16 : 32; }
 
 // packed input (time-major path): the same kernels reading 4-bit resp. 2-bit pieces
 template <int PK>
@@ -322,6 +324,8 @@ static int dispatch_encode(const mh_plan *p, const mh::Enc2Args &a2, hipStream_t
         case 11: return launch_encode2<0, 3, 11>(a2, st);
         case 12: return launch_encode2<0, 3, 12>(a2, st);
         case 13: return launch_encode2<0, 3, 13>(a2, st);
+        case 14: return launch_encode2<0, 3, 14>(a2, st);
+        case 15: return launch_encode2<0, 3, 15>(a2, st);
         default: return launch_encode2<0, 3, 8>(a2, st);
         }
     }

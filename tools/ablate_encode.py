@@ -23,9 +23,10 @@ enc = plan.alloc_encoded()
 lib = muahuff._lib.lib()
 names = {0: "full", 1: "no global stores", 2: "+ no scan/merge", 3: "+ no staging writes", 4: "loads only",
          5: "full, plain stores", 6: "full, nt sc1 stores", 7: "full, sc0 sc1 stores", 8: "full, stores kept in L2",
-         11: "loads + typical stores", 12: "rows+staging + typ. stores", 13: "full, stores from regs"}
+         11: "loads + typical stores", 12: "rows+staging + typ. stores", 13: "full, stores from regs",
+         14: "full, no segment-tail store", 15: "14 + no seg_words/ch_bits"}
 for rounds in range(2):
-    for lvl in ((0, 1, 2, 4, 5, 6, 7, 8, 11, 12, 13) if S <= 3 else (0, 1, 2, 4, 8) if S <= 6 else (0, 1, 2, 4)):
+    for lvl in ((0, 1, 4, 8, 11, 14, 15, 0) if S <= 3 else (0, 1, 2, 4, 8) if S <= 6 else (0, 1, 2, 4)):
         lib.mhdbg_set_ablation(lvl)
         plan.encode(cs.data, out=enc)
         torch.cuda.synchronize()
