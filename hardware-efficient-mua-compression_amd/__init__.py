@@ -37,7 +37,7 @@ _sys.modules["muahuff"] = _sys.modules[__name__]
 
 from . import _lib, sclv  # noqa: E402,F401
 from ._lib import (CHUNK, MODE_APPROX, MODE_NOSORT, WIN_AFTER_CAL, WIN_FULL,  # noqa: F401
-                   WIN_REF_HALF, WIN_REF_HALF_TRUNC, MuaHuffError, device_info)
+                   WIN_REF_HALF, WIN_REF_HALF_TRUNC, WIN_REV2_SEGMENTS, MuaHuffError, device_info)
 
 __version__ = "0.1.0"
 

@@ -10,6 +10,7 @@ ERR_ARG, ERR_EMPTY_CHANNEL, ERR_SCLV, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE, ERR_
 
 MODE_NOSORT, MODE_APPROX = 0, 1
 WIN_REF_HALF, WIN_REF_HALF_TRUNC, WIN_AFTER_CAL, WIN_FULL = 0, 1, 2, 3
+WIN_REV2_SEGMENTS = 0x100  # OR-ed into a window rule: the segment directory of container format revision 2 (no head segments)
 
 PIECE, LANES, ROWS = 16, 64, 16
 SUB = PIECE * ROWS

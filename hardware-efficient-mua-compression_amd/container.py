@@ -8,18 +8,28 @@ wavefront reads 1 KiB of one channel per load instruction.
 import numpy as np
 import torch
 
-ALIGN = 16
+ALIGN = 16          # every channel starts on a 16-byte boundary (one piece)
+LINE_ALIGN = 128    # ... and a LONG one on a 128-byte line: with the head segment of container format revision 3
+LONG = 16 * 16384   # (include/muahuff.h, MH_HEAD_ALIGN / MH_HEAD_MIN_WINDOW) all its 1-KiB rows then start on a line
 
 
-def layout(lengths, align=ALIGN):
-    """(ch_off, ch_len, total_bytes) for channels of the given lengths."""
+def layout(lengths, align=None):
+    """(ch_off, ch_len, total_bytes) for channels of the given lengths.  align=None: 16 bytes, 128 for channels of
+    at least 2^18 bins (whose windows get head segments)."""
     ln = np.asarray(lengths, dtype=np.uint64)
-    pad = (ln + np.uint64(align - 1)) & ~np.uint64(align - 1)
+    al = (np.where(ln >= LONG, LINE_ALIGN, ALIGN) if align is None else np.full(len(ln), align)).astype(np.uint64)
     off = np.zeros(len(ln), dtype=np.uint64)
-    if len(ln) > 1:
+    if len(ln) and (al == al[0]).all():      # one alignment throughout: closed form
+        pad = (ln + al - np.uint64(1)) & ~(al - np.uint64(1))
         off[1:] = np.cumsum(pad)[:-1]
-    total = int(pad.sum()) if len(ln) else 0
-    return off, ln, total
+        return off, ln, int(pad.sum())
+    cur = 0
+    for i in range(len(ln)):
+        a = int(al[i])
+        cur = (cur + a - 1) // a * a
+        off[i] = cur
+        cur += int(ln[i])
+    return off, ln, (cur + ALIGN - 1) // ALIGN * ALIGN
 
 
 class ChannelSet:

@@ -1,4 +1,4 @@
-"""Wire / file format of a compressed channel set (format revision 2), and the two calls that
+"""Wire / file format of a compressed channel set (format revision 3; revision 2 is still read), and the two calls that
 make the codec usable end to end: compress() and decompress().
 
 The reference never serialises a bitstream; this container is the
@@ -23,7 +23,9 @@ from dataclasses import dataclass
 import numpy as np
 
 MAGIC = b"MUAHUFF1"
-FORMAT_REVISION = 2
+FORMAT_REVISION = 3          # written; revision 2 (no head segments, include/muahuff.h MH_WIN_REV2_SEGMENTS) is still read
+READ_REVISIONS = (2, 3)
+WIN_REV2_SEGMENTS = 0x100
 
 
 @dataclass
@@ -75,7 +77,7 @@ def read(f):
         raise ValueError("not a MUAHUFF1 container")
     (n,) = struct.unpack("<I", f.read(4))
     hdr = json.loads(f.read(n).decode())
-    if hdr.get("format_revision") != FORMAT_REVISION:
+    if hdr.get("format_revision") not in READ_REVISIONS:
         raise ValueError("unsupported container revision %r" % hdr.get("format_revision"))
     out = {}
     for name, dt in (("ch_len", np.uint64), ("peak", np.uint8), ("enc", np.uint8), ("skipped", np.uint8),
@@ -130,12 +132,25 @@ def compress(cs, S, h, mode, sclv, window=None, seg_chunks=0):
     return c
 
 
-def segments_per_channel(ch_len, h, window, seg_chunks):
+def plan_window(hd):
+    """The `window` argument a plan for this container takes: the header's window rule, plus the flag that selects
+    revision 2's segment directory when a revision-2 stream is read."""
+    return int(hd["window"]) | (WIN_REV2_SEGMENTS if int(hd.get("format_revision", FORMAT_REVISION)) == 2 else 0)
+
+
+def segments_per_channel(ch_len, h, window, seg_chunks, revision=FORMAT_REVISION):
     """Number of directory entries of each channel: the window rule of include/muahuff.h applied
-    to the channel length, cut into segments of seg_chunks chunks (the planner's layout)."""
+    to the channel length, cut into segments of seg_chunks chunks (the planner's layout) -- from revision 3 on
+    behind a head segment up to the next multiple of 128 samples when the window has at least 16 chunks."""
     from . import CHUNK
     seg = int(seg_chunks) * CHUNK
-    return (window_lengths(ch_len, h, window) + seg - 1) // seg
+    n = window_lengths(ch_len, h, window)
+    if int(revision) == 2:
+        return (n + seg - 1) // seg
+    T = np.asarray(ch_len, dtype=np.int64)
+    w0 = np.zeros_like(T) if window == 3 else np.minimum(np.int64(1) << int(h), T)
+    head = np.where((n >= 16 * CHUNK) & (w0 % 128 != 0), 128 - w0 % 128, 0)
+    return (n - head + seg - 1) // seg + (head > 0)
 
 
 def window_lengths(ch_len, h, window):
@@ -191,7 +206,9 @@ def validate(c):
     pay = np.ascontiguousarray(c.payload, np.uint32)
     segw = np.ascontiguousarray(c.seg_words, np.uint64)
     peak, enc = np.ascontiguousarray(c.peak, np.uint8), np.ascontiguousarray(c.enc, np.uint8)
-    rc = _lib.lib().mh_validate_stream(ch_len.ctypes.data, C, S, h, mode, window, rows.ctypes.data, K, seg_chunks,
+    if hd.get("format_revision") not in READ_REVISIONS:
+        raise ValueError("container header: unsupported revision %r" % (hd.get("format_revision"),))
+    rc = _lib.lib().mh_validate_stream(ch_len.ctypes.data, C, S, h, mode, plan_window(hd), rows.ctypes.data, K, seg_chunks,
                                        pay.ctypes.data if pay.size else np.zeros(1, np.uint32).ctypes.data, pay.size,
                                        segw.ctypes.data if segw.size else np.zeros(1, np.uint64).ctypes.data, segw.size,
                                        peak.ctypes.data, enc.ctypes.data)
@@ -212,7 +229,7 @@ def decompress(c, device="cuda", channels=None, check=True):
     if check:
         validate(c)
     hd = c.header
-    nseg_ch = segments_per_channel(c.ch_len, hd["h"], hd["window"], hd["seg_chunks"])
+    nseg_ch = segments_per_channel(c.ch_len, hd["h"], hd["window"], hd["seg_chunks"], hd.get("format_revision", FORMAT_REVISION))
     if int(nseg_ch.sum()) != len(c.seg_words):
         raise ValueError("container directory does not match its header")
     seg_words, payload, peak, enc, skipped, ch_bits, ch_len = (c.seg_words, c.payload, c.peak, c.enc, c.skipped,
@@ -231,7 +248,7 @@ def decompress(c, device="cuda", channels=None, check=True):
     cs = ChannelSet.empty([int(n) for n in ch_len], device=device)
     if len(ch_len) == 0:
         return cs
-    plan = codec.Plan(cs.ch_off, cs.ch_len, hd["S"], hd["h"], hd["mode"], hd["window"],
+    plan = codec.Plan(cs.ch_off, cs.ch_len, hd["S"], hd["h"], hd["mode"], plan_window(hd),
                       np.array(hd["sclv"], np.uint8), seg_chunks=hd["seg_chunks"])
     if plan.n_segments != len(seg_words):
         raise ValueError("container directory does not match its header")

@@ -139,6 +139,14 @@ struct PlanTuning {  // MH_TUNING builds only; the defaults are the measured bes
     int wave_tasks = -1;  // -1 = planner's rule, 0 / 1 = force
 };
 
+// Head segment of a window [w0, w1) (container format revision 3, include/muahuff.h): samples up to the next
+// multiple of MH_HEAD_ALIGN when the window is long enough for the alignment of its rows to matter.
+inline uint64_t head_samples(uint64_t w0, uint64_t w1, uint32_t window)
+{
+    if ((window & MH_WIN_REV2_SEGMENTS) || w1 - w0 < MH_HEAD_MIN_WINDOW || w0 % MH_HEAD_ALIGN == 0) return 0;
+    return MH_HEAD_ALIGN - w0 % MH_HEAD_ALIGN;
+}
+
 // windows of one channel: c = min(2^h, T) (functions_1.py:59-64), e = c + T/2 (get_BR_with_approx_sort.py:180)
 inline void channel_window(uint64_t T, uint32_t h, uint32_t window, uint64_t *w0, uint64_t *w1, uint8_t *skip)
 {
@@ -173,7 +181,7 @@ inline int plan_check_args(const uint64_t *ch_len, uint32_t C, uint32_t S, uint3
     if (S < 2 || S > 10) { *msg = "S=%u outside 2..10"; *msg_arg = S; return MH_ERR_ARG; }
     if (h > 30) { *msg = "h=%u outside 0..30"; *msg_arg = h; return MH_ERR_ARG; }
     if (mode > MH_MODE_APPROX) { *msg = "mode=%u unknown"; *msg_arg = mode; return MH_ERR_ARG; }
-    if (window > MH_WIN_FULL) { *msg = "window=%u unknown"; *msg_arg = window; return MH_ERR_ARG; }
+    if ((window & ~MH_WIN_REV2_SEGMENTS) > MH_WIN_FULL) { *msg = "window=%u unknown"; *msg_arg = window; return MH_ERR_ARG; }
     if (K == 0 || K > 255) { *msg = "K=%u outside 1..255"; *msg_arg = K; return MH_ERR_ARG; }
     uint32_t maxlen = 0;
     for (uint32_t k = 0; k < K; ++k) {
@@ -211,7 +219,7 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
     for (uint32_t c = 0; c < C; ++c) {
         const uint64_t T = ch_len[c];
         if (T > p.max_T) p.max_T = T;
-        channel_window(T, I.h, I.window, &p.w0[c], &p.w1[c], &p.skip[c]);
+        channel_window(T, I.h, I.window & ~MH_WIN_REV2_SEGMENTS, &p.w0[c], &p.w1[c], &p.skip[c]);
         nskip += p.skip[c];
         total += p.w1[c] - p.w0[c];
     }
@@ -236,14 +244,31 @@ inline void plan_host_build(PlanHost &p, const uint64_t *ch_off, const uint64_t 
     p.slot_full = slot_words(seg_samples, I.maxlen);
     for (uint32_t c = 0; c < C; ++c) {
         const uint64_t n = p.w1[c] - p.w0[c];
-        const size_t seg_begin = p.seg_ch.size();
-        for (uint64_t first = 0; first < n; first += seg_samples) {
-            const uint64_t m = n - first < seg_samples ? n - first : seg_samples;
+        size_t seg_begin = p.seg_ch.size();
+        auto add_segment = [&](uint64_t first, uint64_t m) {
             p.seg_ch.push_back(c);
             p.seg_first.push_back(first);
             p.seg_n.push_back(m);
             p.seg_off.push_back(slot);
             slot += slot_words(m, I.maxlen);
+        };
+        const uint64_t head = head_samples(p.w0[c], p.w1[c], I.window);
+        if (head) add_segment(0, head);
+        for (uint64_t first = head; first < n; first += seg_samples)
+            add_segment(first, n - first < seg_samples ? n - first : seg_samples);
+        if (head) {  // the head segment is a task of its own: the regular ones stay an arithmetic sequence
+            WgTask t{};
+            t.src_off = ch_off[c] + src_bytes(p.w0[c]);
+            t.dst_off = p.seg_off[seg_begin];
+            t.n_last = (uint32_t)head;
+            t.ch = c;
+            t.seg0 = (uint32_t)seg_begin;
+            t.nseg = 1;
+            p.task_seg0.push_back((uint32_t)seg_begin);
+            p.task_n.push_back(1);
+            p.wg_tasks.push_back(t);
+            padded_waves += 1;  // (its three idle waves leave at once: not what the wave-task rule below is about)
+            ++seg_begin;
         }
         for (size_t s0 = seg_begin; s0 < p.seg_ch.size(); s0 += 4) {
             const uint32_t cnt = (uint32_t)(p.seg_ch.size() - s0 < 4 ? p.seg_ch.size() - s0 : 4);

@@ -551,7 +551,7 @@ int mh_plan_create_packed(mh_plan **plan, const uint64_t *ch_off, const uint64_t
     *plan = nullptr;
     if (input_bits != 8 && input_bits != 4 && input_bits != 2)
         return fail(MH_ERR_ARG, "input_bits=%u (8, 4 or 2)", input_bits);
-    if (input_bits != 8 && window != MH_WIN_FULL)
+    if (input_bits != 8 && (window & ~MH_WIN_REV2_SEGMENTS) != MH_WIN_FULL)
         return fail(MH_ERR_ARG, "packed input needs the whole-channel window (MH_WIN_FULL)");
     if (input_bits == 2 && S > 4) return fail(MH_ERR_ARG, "2-bit input holds symbols 0..3: S=%u is above 4", S);
     if (chunk_stride && (input_bits == 8 || chunk_stride % 16 || chunk_stride < (uint64_t)MH_CHUNK * input_bits / 8))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MH_VERSION 102 /* 0.1.2 ; container format revision 2 */
+#define MH_VERSION 103 /* 0.1.3 ; container format revision 3 (reads revision 2) */
 
 /* ---- error codes -------------------------------------------------------------------- */
 #define MH_OK 0
@@ -67,6 +67,17 @@ extern "C" {
 #define MH_WIN_AFTER_CAL 2      /* [c, T)  : compress everything after calibration             */
 #define MH_WIN_FULL 3           /* [0, T)  : whole channel (training histograms,
                                    Compressing data/get_BR_with_approx_sort.py:140-147)        */
+/* How a window is cut into segments (part of the container format; the reference has no bitstream).
+ * Revision 3, the default: a window of at least MH_HEAD_MIN_WINDOW samples that does not start at a multiple of
+ * MH_HEAD_ALIGN samples begins with a short HEAD segment ending at the next multiple; the regular segments
+ * (seg_chunks chunks each) follow.  With the calibration cutoffs of the reference (c = 2^2 .. 2^6 samples) every
+ * 1-KiB row a wavefront loads or stores would otherwise start 4 .. 64 bytes into a 128-byte line of a line-aligned
+ * channel and straddle nine lines instead of eight (1024 ch x 1e7 bins: decode -2 .. -7 %, encode -1.5 .. -4 %).
+ * MH_WIN_REV2_SEGMENTS, OR-ed into the `window` argument, cuts every window from its first sample as revision 2
+ * did: that is how streams stored by revision 2 are read. */
+#define MH_WIN_REV2_SEGMENTS 0x100u
+#define MH_HEAD_ALIGN 128
+#define MH_HEAD_MIN_WINDOW (16 * MH_CHUNK)
 
 typedef struct mh_plan mh_plan; /* opaque */
 
@@ -99,7 +110,7 @@ int mh_approx_sort_perm(int S, int peak, uint8_t *idx);
  * (channel i = bytes [ch_off[i], ch_off[i]+ch_len[i]) ; the in-memory form of
  * all_binned_data[BP][dataset][channel], Data/get_all_binned_data.py:62-64) and fixes the
  * design point: S (symbols 0..S-1), h (calibration window 2^h samples), mapper mode,
- * window rule, K candidate encoders given as SCLV rows (host, K*S bytes, row order =
+ * window rule (MH_WIN_*, optionally | MH_WIN_REV2_SEGMENTS), K candidate encoders given as SCLV rows (host, K*S bytes, row order =
  * encoder index, first-min tie-break as np.argmin).  Precomputes windows, the segment
  * directory and codebooks and uploads them.  ch_off, ch_len, sclv: host.
  * seg_chunks = chunks per segment (the unit one wavefront encodes / decodes); 0 lets the planner

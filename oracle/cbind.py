@@ -15,6 +15,7 @@ HDR_WORDS = LANES // 2
 
 MODE_NOSORT, MODE_APPROX = 0, 1
 WIN_REF_HALF, WIN_REF_HALF_TRUNC, WIN_AFTER_CAL, WIN_FULL = 0, 1, 2, 3
+WIN_REV2_SEGMENTS = 0x100  # OR-ed into a window rule: format revision 2's segment directory (no head segments)
 
 
 def build(force=False):

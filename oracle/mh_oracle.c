@@ -154,7 +154,7 @@ int mho_calibrate(const uint8_t *x, uint64_t T, const mho_params *p, mho_chan *o
     out->enc = (uint8_t)mho_select_encoder(out->cal_sorted, p->sclv, (int)p->K, S);
     const uint64_t e = c + T / 2; /* :180  int(len/2) */
     out->skipped = 0;
-    switch (p->window) {
+    switch (p->window & ~MHO_WIN_REV2_SEGMENTS) {
     case MHO_WIN_REF_HALF:
         if (e > T) { /* :183-185 */
             out->skipped = 1;
@@ -272,7 +272,7 @@ static void window_of(uint64_t T, const mho_params *p, uint64_t *w0, uint64_t *w
 {
     const uint64_t c = mho_cutoff(T, (uint64_t)1 << p->h), e = c + T / 2;
     *skipped = 0;
-    switch (p->window) {
+    switch (p->window & ~MHO_WIN_REV2_SEGMENTS) {
     case MHO_WIN_REF_HALF:
         if (e > T) { *skipped = 1; *w0 = *w1 = c; } else { *w0 = c; *w1 = e; }
         break;
@@ -294,8 +294,14 @@ uint64_t mho_plan_segments(const uint64_t *ch_len, uint32_t C, const mho_params 
         int sk;
         window_of(ch_len[c], p, &w0, &w1, &sk);
         const uint64_t n = w1 - w0;
-        for (uint64_t first = 0; first < n; first += seg_samples) {
-            const uint64_t m = n - first < seg_samples ? n - first : seg_samples;
+        /* container format revision 3: a long window that starts off a 128-sample boundary opens with a head
+         * segment up to that boundary (include/muahuff.h, MH_WIN_REV2_SEGMENTS) */
+        uint64_t head = 0;
+        if (!(p->window & MHO_WIN_REV2_SEGMENTS) && n >= MHO_HEAD_MIN_WINDOW && w0 % MHO_HEAD_ALIGN)
+            head = MHO_HEAD_ALIGN - w0 % MHO_HEAD_ALIGN;
+        for (uint64_t first = 0; first < n; first += (first == 0 && head) ? head : seg_samples) {
+            uint64_t m = n - first < seg_samples ? n - first : seg_samples;
+            if (first == 0 && head) m = head;
             if (seg_ch) {
                 seg_ch[nseg] = c;
                 seg_first[nseg] = first;

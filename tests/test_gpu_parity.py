@@ -430,6 +430,106 @@ def test_encode_decode_are_graph_capturable(mh, S):
     plan.close()
 
 
+@pytest.mark.parametrize("S,h,window", [(3, 6, 2), (5, 2, 2), (3, 6, 0), (8, 7, 2), (3, 5, 1)])
+def test_head_segments_of_format_revision_3_vs_oracle(mh, S, h, window):
+    """Container format revision 3: a window of >= 16 chunks that starts off a 128-sample boundary opens with a
+    HEAD segment up to that boundary (include/muahuff.h).  Directory, every segment's words and the decode are
+    byte-exact against the oracle -- for long and short channels side by side, windows just below / at the
+    length limit, and with MH_WIN_REV2_SEGMENTS (revision 2's directory: no head anywhere)."""
+    from muahuff import container_io as cio
+    rng = np.random.RandomState(77 + S + h)
+    lim = 16 * mh.CHUNK
+    c = 2 ** h
+    # window length == lim needs T - c == lim for [c, T) and T // 2 == lim for the half windows
+    lens = [lim + c - 1, lim + c, lim + c + 1, 2 * lim + 1, 2 * lim, 2 * lim + 2, 300001, 70001, 5, 3 * lim + 777]
+    chans = _channels(rng, lens, 0.2, 3.0)
+    cs = _cs(mh, chans)
+    assert all(int(o) % 128 == 0 for o, n in zip(cs.ch_off, cs.ch_len) if n >= lim)   # long channels sit on a line
+    tab = helpers.sclv_tables()[S]
+    host = cs.data.cpu().numpy()
+    for flag in (0, mh.WIN_REV2_SEGMENTS):
+        plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, 1, window | flag, tab, seg_chunks=2)
+        p = OC.Params(S, h, 1, window | flag, tab, seg_chunks=2)
+        e, oe = plan.encode(cs.data), OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+        seg = plan.segments()
+        for k in ("ch", "first", "n", "off"):
+            assert np.array_equal(seg[k], oe["seg"][k]), k
+        # the rule itself, restated: which channels have a head segment, and how long it is
+        heads = {}
+        for ch, x in enumerate(chans):
+            w0, w1 = _window(len(x), h, window)
+            if not flag and w1 - w0 >= lim and w0 % 128:
+                heads[ch] = 128 - w0 % 128
+        first_of = {}
+        for sidx, ch in enumerate(seg["ch"]):
+            first_of.setdefault(int(ch), sidx)
+        for ch, sidx in first_of.items():
+            assert int(seg["n"][sidx]) == heads.get(ch, min(int(seg["n"][sidx]), 2 * mh.CHUNK)), ch
+            if ch in heads:   # every later segment of the channel starts on a 128-sample boundary of the channel
+                w0 = _window(len(chans[ch]), h, window)[0]
+                later = [int(f) for f, c2 in zip(seg["first"], seg["ch"]) if c2 == ch][1:]
+                assert later and all((w0 + f) % 128 == 0 for f in later)
+        assert (len(heads) > 0) == (flag == 0 and c % 128 != 0)
+        rev = 2 if flag else 3
+        assert np.array_equal(cio.segments_per_channel(cs.ch_len, h, window, 2, rev), np.bincount(seg["ch"], minlength=len(chans)))
+        sw = e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments]
+        assert np.array_equal(sw, oe["seg_words"])
+        assert np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+        pay = e.payload.cpu().numpy().view(np.uint32)
+        for sidx in range(plan.n_segments):
+            o, n = int(seg["off"][sidx]), int(sw[sidx])
+            assert np.array_equal(pay[o:o + n], oe["payload"][o:o + n]), "segment %d" % sidx
+        out = torch.full_like(cs.data, 0xEE)
+        plan.decode(e, out)
+        assert plan.decode_ok()
+        got = out.cpu().numpy()
+        for ch, x in enumerate(chans):
+            w0, w1 = _window(len(x), h, window)
+            o = int(cs.ch_off[ch])
+            assert np.array_equal(got[o + w0:o + w1], np.minimum(x[w0:w1], S - 1)), ch
+            assert np.all(got[o:o + w0] == 0xEE) and np.all(got[o + w1:o + len(x)] == 0xEE), ch
+        plan.close()
+
+
+def test_revision_2_containers_are_still_read(mh, tmp_path):
+    """A stream written with revision 2's directory (MH_WIN_REV2_SEGMENTS) and labelled format_revision 2 -- what the
+    previous release stored -- validates, loads and decompresses; the same data written now is revision 3 and has
+    one more segment per long channel."""
+    from muahuff import container_io as cio
+    rng = np.random.RandomState(5)
+    chans = _channels(rng, [16 * mh.CHUNK + 1000, 50000, 20 * mh.CHUNK + 3], 0.2, 3.0)
+    cs = _cs(mh, chans)
+    tab = helpers.sclv_tables()[3]
+    new = cio.compress(cs, 3, 6, 1, tab)
+    assert new.header["format_revision"] == 3
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 1, mh.WIN_AFTER_CAL | mh.WIN_REV2_SEGMENTS, tab, seg_chunks=new.header["seg_chunks"])
+    e = plan.encode(cs.data)
+    d, tot = plan.compact(e)
+    total = int(tot.item())
+    hdr = dict(new.header)
+    hdr["format_revision"] = 2
+    old = cio.Compressed(hdr, cs.ch_len.copy(), e.peak.cpu().numpy(), e.enc.cpu().numpy(), e.skipped.cpu().numpy(),
+                         e.ch_bits.cpu().numpy().astype(np.uint64), e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments],
+                         d.payload[:total].cpu().numpy().view(np.uint32).copy())
+    plan.close()
+    assert len(new.seg_words) == len(old.seg_words) + 2        # two long channels -> two head segments
+    assert np.array_equal(new.ch_bits, old.ch_bits)            # the same code bits either way
+    fn = str(tmp_path / "rev2.muahuff")
+    cio.save(fn, old)
+    back = cio.load(fn)
+    assert back.header["format_revision"] == 2
+    cio.validate(back)
+    for c_ in (back, new):
+        got = cio.decompress(c_).to_channels()
+        for x, y in zip(chans, got):
+            assert np.array_equal(y[64:], np.minimum(x[64:], 2))
+    # mislabelled: a revision-2 directory read as revision 3 does not match
+    hdr3 = dict(hdr)
+    hdr3["format_revision"] = 3
+    with pytest.raises(ValueError):
+        cio.decompress(cio.Compressed(hdr3, old.ch_len, old.peak, old.enc, old.skipped, old.ch_bits, old.seg_words, old.payload))
+
+
 def test_decode_status_is_sticky_across_graph_replays_and_direct_calls(mh):
     """A captured decode carries no per-call state, so the status word is a sticky flag: a corrupt stream that
     goes through a REPLAYED graph is reported even when direct decodes on the same plan happened after the

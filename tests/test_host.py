@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     raw = ct.CDLL(_lib.SO)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib().mh_version() == 102
+    assert _lib.lib().mh_version() == 103
 
 
 def test_graft_entry_build_runs():
@@ -181,7 +181,7 @@ def test_container_file_roundtrip_without_gpu(tmp_path):
     fn = tmp_path / "x.mhf"
     cio.save(fn, c)
     d = cio.load(fn)
-    assert d.header["S"] == 3 and d.header["sclv"] == [[1, 2, 2]] and d.header["format_revision"] == 2
+    assert d.header["S"] == 3 and d.header["sclv"] == [[1, 2, 2]] and d.header["format_revision"] == 3
     for name in ("ch_len", "peak", "enc", "skipped", "ch_bits", "seg_words", "payload"):
         assert np.array_equal(getattr(c, name), getattr(d, name)), name
     assert d.container_bits == 35 * 32 and d.payload_bits == 51
