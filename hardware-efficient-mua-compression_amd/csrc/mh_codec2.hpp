@@ -607,12 +607,21 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
 // and only the one cut piece (m % 16 samples, in lane (m / 16) % 64, that lane's last piece) goes
 // symbol by symbol.  Same staging and the same in-place merge.
 // Returns {words, bits, new pend, words by which dst advanced}.
+// (Out of line, so its pointer arguments carry their address spaces in the signature: as generic pointers every
+// table lookup and staging access in here was a FLAT instruction -- slower than ds_read / global_load and counted
+// on both wait counters.  Short channels spend a fifth of their samples in this function.)
+#define MH_AS_GLOBAL __attribute__((address_space(1)))
+#define MH_AS_LDS __attribute__((address_space(3)))
 template <int LC, int PB, int PK>
-__device__ __noinline__ uint4 encode_partial_chunk(const uint8_t *__restrict__ src, uint32_t m, const uint2 *lut2,
-                                                   const uint2 *lut1, uint32_t *buf, uint32_t cap,
-                                                   uint32_t *__restrict__ dst0, uint32_t pend, int lane)
+__device__ __noinline__ uint4 encode_partial_chunk(const MH_AS_GLOBAL uint8_t *src_g, uint32_t m, const MH_AS_LDS uint2 *lut2_l,
+                                                   const MH_AS_LDS uint2 *lut1_l, MH_AS_LDS uint32_t *buf_l, uint32_t cap,
+                                                   MH_AS_GLOBAL uint32_t *dst0_g, uint32_t pend, int lane)
 {
     constexpr int NE = stage_ne(LC), MH_NE_ = NE;
+    const uint8_t *__restrict__ src = (const uint8_t *)src_g;
+    const uint2 *lut2 = (const uint2 *)lut2_l, *lut1 = (const uint2 *)lut1_l;
+    uint32_t *buf = (uint32_t *)buf_l;
+    uint32_t *__restrict__ dst0 = (uint32_t *)dst0_g;
     uint32_t *__restrict__ dst = dst0;
     uint32_t words, bits;
     uint64_t acc = 0;
@@ -717,7 +726,9 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
         bits += b;
     }
     if (rem) {
-        const uint4 r = encode_partial_chunk<LC, PB, PK>(src + (size_t)nfull * cstride, rem, lut2, lut1, buf, cap, out, pend, lane);
+        const uint4 r = encode_partial_chunk<LC, PB, PK>((const MH_AS_GLOBAL uint8_t *)(src + (size_t)nfull * cstride), rem,
+                                                         (const MH_AS_LDS uint2 *)lut2, (const MH_AS_LDS uint2 *)lut1,
+                                                         (MH_AS_LDS uint32_t *)buf, cap, (MH_AS_GLOBAL uint32_t *)out, pend, lane);
         words += r.x;
         bits += r.y;
         pend = r.z;

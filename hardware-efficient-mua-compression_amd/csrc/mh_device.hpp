@@ -81,6 +81,17 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v)
     return v;
 }
 
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, d, 64), hi = __shfl_xor((uint32_t)(v >> 32), d, 64);
+        const uint64_t t = (uint64_t)lo | ((uint64_t)hi << 32);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 {
 #pragma unroll

@@ -164,6 +164,7 @@ static mh::CalArgs calibrate_args(const mh_plan *p, const uint8_t *data, uint64_
     a.ch_off = p->d_ch_off;
     a.ch_len = p->d_ch_len;
     a.sclv = p->d_sclv;
+    a.sclv16 = p->d_sclv16;
     a.codes = p->d_codes;
     a.C = I.C;
     a.S = I.S;
