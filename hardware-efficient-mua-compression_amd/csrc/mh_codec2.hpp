@@ -941,7 +941,12 @@ __global__ __launch_bounds__(256, 4) void k_encode2w(Enc2Args a)
         // channel's word in plan scratch with ONE returning device-scope atomic.  The record that sees
         // nseg_ch - 1 earlier tickets in the returned value is the last one: the returned total plus its
         // own bits is the channel's total; it stores it and leaves the scratch zero for the next launch.
-        // (The planner only enables this when ticket count and bit total fit their 24 / 40 bits.)
+        // (The planner only enables this when ticket count and bit total fit their 24 / 40 bits:
+        // PlanHost::tickets_fit, checked at both edges by tests/planner_check.cpp.)
+        // Ordering: there is nothing to order.  Count AND payload travel in the same 64-bit agent-scope RMW, and the
+        // operations on acc[ch] form one total order: the value a record gets back is exactly the sum of the
+        // records before it in that order, whichever XCDs they ran on.  The final ch_bits store is a plain store by
+        // one wave, visible at the end of the kernel like every other output; the atomicExch re-arms the word.
         const unsigned long long before = atomicAdd(&a.e.acc[t.ch], ((unsigned long long)bits << 24) | 1ull);
         if ((uint32_t)(before & 0xFFFFFFull) + 1u == t.nseg_ch) {
             a.e.ch_bits[t.ch] = (before >> 24) + bits;

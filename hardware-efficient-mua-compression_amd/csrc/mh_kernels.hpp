@@ -250,12 +250,42 @@ __device__ __forceinline__ void hist_add(unsigned long long *bin, uint32_t v, bo
 }
 
 // call at the very end of a window-histogram kernel, after the workgroup's hist_adds into a.hist
+//
+// The one-launch measure passes counts between workgroups -- on any of the 8 XCDs, whose L2s are not coherent with
+// each other for ordinary accesses -- WITHOUT fences.  It is the hand-off the MI355X guide lists as valid with
+// "8-byte agent-scope atomics on both sides" and "the workgroup whose add came last, told by the value its add
+// returned" (MI355X_MICROARCH.md, inter-workgroup visibility).  Why a count can never be read before it has landed:
+//
+//  (1) Every add into hist[ch][bin] and every ticket on tile_done[ch] is an agent-scope atomic RMW: the operations
+//      on one address form a single total order, whichever XCD issued them (they are not satisfied from a line an
+//      XCD's L2 happens to hold; an atomic drops the line from the issuing L2).
+//  (2) hist_add asks for the RETURNING form and consumes the result (`asm volatile("" :: "v"(before))`): the
+//      compiler has to wait for it there, and the pre-op value only comes back once the add HAS BEEN PERFORMED.
+//      ISA of k_hist<2> (hipcc 7.2, gfx950):   global_atomic_add_x2 v[2:3], v1, v[2:3], s[4:5] sc0
+//                                              s_waitcnt vmcnt(0)
+//                                              ...  s_barrier
+//                                              global_atomic_add v2, v2, v3, s[28:29] sc0        <- the ticket
+//  (3) The s_barrier therefore separates "all 256 threads' adds are performed" from the ticket: thread 0 ISSUES the
+//      ticket atomic only after the barrier, i.e. after (2) held for every add of this workgroup.
+//  (4) Tickets on one address are totally ordered (1).  The workgroup whose ticket returns tile_cnt - 1 issued it
+//      after every other workgroup's ticket was performed, each of which was issued after that workgroup's adds
+//      were performed (3): when the last arriver's ticket RETURNS, every add of the channel precedes, in the total
+//      order of its bin, anything the last arriver does next.
+//  (5) The last arriver reads the bins with agent-scope atomic LOADS (finalize_channel<true>:
+//      __hip_atomic_load(.., __HIP_MEMORY_SCOPE_AGENT) -> `global_load_dwordx2 .. sc1`), issued after (4) by data
+//      dependence (s_last through LDS + barrier).  An sc1 load is not served from this CU's L1 nor from a stale
+//      line: it observes all adds of (4).  (The plain loads in calibrate_channel read the caller's input data only.)
+//  (6) Re-arming: the last arriver zeroes the channel's 16 bins (one 128-byte line per channel: nobody else's) and its
+//      ticket with PLAIN stores.  Nothing of this launch touches them afterwards (all tiles have arrived); the
+//      stores are written back at the end of the kernel, which is ordered before the next launch on the stream.
+//
+// What is NOT relied on: any ordering between plain stores and atomics of different workgroups, any L2 state across
+// XCDs, or in-order retirement across addresses beyond "a returned value means performed".  The textbook form -- an
+// agent-scope release before the ticket, an acquire in the last arriver -- writes back / invalidates caches per
+// workgroup and made this kernel 10x slower.
+// tests/test_gpu_parity.py::test_fused_measure_at_its_limits runs it at 4096 channels x 4 tiles, 2^12 calibration.
 __device__ __forceinline__ void measure_tail(const HistArgs &a, uint32_t ch)
 {
-    // No fences: the counts travel by device-scope atomics whose RETURN the adding threads have waited for
-    // (hist_add), the ticket is a device-scope atomic, and the last arriver reads the counts with device-scope
-    // atomic loads -- nothing here goes through a cache that would have to be written back or invalidated
-    // (an agent-scope fence per workgroup made this kernel 10x slower).
     if (!a.tile_cnt) return;
     __shared__ uint32_t s_last;
     __syncthreads();   // every count of this workgroup has been added (and acknowledged)

@@ -131,7 +131,8 @@ int main()
             for (unsigned c = 0; c < C; ++c) cal_want += len[c] < ((uint64_t)1 << h) ? len[c] : ((uint64_t)1 << h);
         CHECK(cal == cal_want);
         CHECK(p.W >= maxlen && p.W <= 12 && (p.dec_K == 2 || p.dec_K == 4));
-        printf("%zu %llu %u %d\n", n, (unsigned long long)p.info.payload_cap_words, p.info.seg_chunks, (int)p.use_wave_tasks);
+        printf("%zu %llu %u %d %d\n", n, (unsigned long long)p.info.payload_cap_words, p.info.seg_chunks, (int)p.use_wave_tasks,
+               (int)p.tickets_fit);
         for (size_t s = 0; s < n; ++s) printf("%u ", p.seg_ch[s]);
         printf("\n");
         for (size_t s = 0; s < n; ++s) printf("%llu ", (unsigned long long)p.seg_first[s]);

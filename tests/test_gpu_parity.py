@@ -530,6 +530,48 @@ def test_revision_2_containers_are_still_read(mh, tmp_path):
         cio.decompress(cio.Compressed(hdr3, old.ch_len, old.peak, old.enc, old.skipped, old.ch_bits, old.seg_words, old.payload))
 
 
+def test_fused_measure_at_its_limits(mh):
+    """The one-launch measure (counts and tickets passed between workgroups by agent-scope atomics, no fences:
+    csrc/mh_kernels.hpp measure_tail) at the edge of what the planner lets it serve: 4096 channels, 16384 tiles
+    (4 per channel), 2^12-sample calibration windows, every encoder of S = 5 and S = 10 -- against the oracle, three
+    launches in a row (the scratch must come back zeroed) and once more from a hipGraph replay."""
+    C, h = 4096, 12
+    T = 2 * (4 * 131072 - 1000)            # [c, c + T/2): 4 tiles of 128 KiB, the last one cut
+    cs = mh.synth.generate(C, T, seed=11, lo=0.05, hi=4.0)
+    host = cs.data.cpu().numpy()
+    for S in (5, 10):
+        tab = helpers.sclv_tables()[S]
+        plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, h, 1, mh.WIN_REF_HALF, tab)
+        om = OC.measure(host, cs.ch_off, cs.ch_len, OC.Params(S, h, 1, OC.WIN_REF_HALF, tab), nthreads=16)
+        m = plan.measure(cs.data)
+
+        def check():
+            assert np.array_equal(m.peak.cpu().numpy(), om["peak"])
+            assert np.array_equal(m.enc.cpu().numpy(), om["enc"])
+            assert np.array_equal(m.post_hist.cpu().numpy().astype(np.uint64), om["post_mapped"])
+            assert np.array_equal(m.bits.cpu().numpy().astype(np.uint64), om["bits"])
+            assert np.array_equal(m.cal_hist.cpu().numpy().astype(np.uint32), om["cal_sorted"])
+        check()
+        for _ in range(2):
+            m.bits.zero_()
+            m.post_hist.zero_()
+            plan.measure(cs.data, out=m)
+            check()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            plan.measure(cs.data, out=m)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            plan.measure(cs.data, out=m)
+        m.bits.zero_()
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+        check()
+        plan.close()
+
+
 def test_decode_status_is_sticky_across_graph_replays_and_direct_calls(mh):
     """A captured decode carries no per-call state, so the status word is a sticky flag: a corrupt stream that
     goes through a REPLAYED graph is reported even when direct decodes on the same plan happened after the

@@ -44,7 +44,33 @@ def _cases():
     cases.append((10, 10, 1, 2, tabs[10], 0, [10_000_000] * 1250))
     cases.append((3, 6, 1, 2, tabs[3], 0, [72_000] * 2400))
     cases.append((5, 30, 0, 3, tabs[5], 1, [2 ** 22 + 1, 5]))
+    # container format revision 3: head segments (windows of >= 16 chunks that start off a 128-sample boundary), next
+    # to channels just below the limit -- and revision 2's directory (MH_WIN_REV2_SEGMENTS = 0x100) for the same layouts
+    lim = 16 * 16384
+    for h, window in ((6, 2), (2, 2), (5, 0), (7, 2), (6, 1)):
+        lens = [lim + 2 ** h - 1, lim + 2 ** h, 2 * lim + 3, 300_001, 70_001, 5, 3 * lim + 777, 2 * lim, 2 * lim + 2]
+        cases.append((3, h, 1, window, tabs[3], 2, lens))
+        cases.append((3, h, 1, window | 0x100, tabs[3], 2, lens))
+        cases.append((8, h, 1, window, tabs[8], 0, lens))
     return cases
+
+
+def test_ticket_word_guard_of_the_wave_task_encoder(exe):
+    """The wave-task encoder packs {bits << 24 | finished records} of a channel into one 64-bit word (k_encode2w);
+    the planner may only enable that when both fields fit: fewer than 2^24 records per channel and a bit total
+    below 2^40 (9 bits x samples: channels shorter than 2^36).  Both sides of the length edge, under the sanitizers."""
+    tab = helpers.sclv_tables()[3]
+    rows = " ".join(str(int(v)) for v in tab.ravel())
+    text = []
+    for big in (2 ** 36 - 1, 2 ** 36):
+        lens = [big] + [100] * 400        # many one-segment channels: the planner chooses wave tasks
+        text.append("%d 3 6 1 2 %d 4096  %s  %s" % (len(lens), len(tab), " ".join(map(str, lens)), rows))
+    r = subprocess.run([exe], input="\n".join(text) + "\n", capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    first = [[int(v) for v in lines[5 * i].split()] for i in range(2)]
+    assert first[0][3] == 1 and first[1][3] == 1          # wave tasks in both
+    assert first[0][4] == 1 and first[1][4] == 0          # the packed word is used below 2^36 samples only
 
 
 def test_planner_under_asan_ubsan_matches_oracle_directory(exe):
@@ -60,7 +86,7 @@ def test_planner_under_asan_ubsan_matches_oracle_directory(exe):
     assert len(lines) == 5 * len(cases)
     OC = oracle.c
     for i, (S, h, mode, window, tab, sc, lens) in enumerate(cases):
-        nseg, cap, sc_used, wave = (int(v) for v in lines[5 * i].split())
+        nseg, cap, sc_used, wave, _tickets = (int(v) for v in lines[5 * i].split())
         if sc == 0:
             assert sc_used in (1, 2)
         else:
