@@ -39,7 +39,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 RC_GATHER_STUCK, RC_GATHER_FAILED, RC_BAD_LAUNCH = 3, 4, 2
 
@@ -290,8 +290,8 @@ def configs3_block(a, rank, world, dist, coll_dev, tab):
         ok, c = True, 2 ** h
         for c0 in range(0, n_ch, 64):
             c1 = min(n_ch, c0 + 64)
-            vin = cs.data[c0 * T:c1 * T].view(c1 - c0, T)[:, c:]
-            vout = out[c0 * T:c1 * T].view(c1 - c0, T)[:, c:]
+            vin = cs.matrix()[c0:c1, c:]
+            vout = cs.matrix(out)[c0:c1, c:]
             ok = ok and bool(torch.equal(torch.clamp(vin, max=S - 1), vout))
         okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
         if dist is not None:
@@ -500,8 +500,8 @@ def main(argv=None):
     ok = None
     if a.verify:
         c = 2 ** h
-        vin = cs.data[:C * T].view(C, T)[:, c:]
-        vout = out[:C * T].view(C, T)[:, c:]
+        vin = cs.matrix()[:, c:]
+        vout = cs.matrix(out)[:, c:]
         ok = bool(torch.equal(torch.clamp(vin, max=S - 1), vout))
         if dist is not None:  # every rank's shard, not just rank 0's
             okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)

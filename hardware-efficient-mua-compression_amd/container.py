@@ -48,6 +48,19 @@ class ChannelSet:
     def device(self):
         return self.data.device
 
+    def matrix(self, buf=None):
+        """[C, T] strided view of the channels (all of one length) in `buf` -- the set's own buffer, or another
+        one laid out like it (a decoder's output).  Channel starts are padded (16 bytes; 128 for channels of >= 2^18
+        bins), so this is the set's buffer seen with a row pitch -- not a reshape of its first C * T bytes."""
+        buf = self.data if buf is None else buf
+        if self.C == 0:
+            return buf[:0].view(0, 0)
+        T = int(self.ch_len[0])
+        if not (self.ch_len == self.ch_len[0]).all():
+            raise ValueError("matrix(): channels of different lengths")
+        pitch = int(self.ch_off[1] - self.ch_off[0]) if self.C > 1 else T
+        return torch.as_strided(buf, (self.C, T), (pitch, 1), int(self.ch_off[0]))
+
     @classmethod
     def from_channels(cls, channels, device="cuda"):
         """channels: list of 1-D arrays of counts (values above 255 saturate like MATLAB uint8)."""

@@ -118,7 +118,7 @@ def test_config3_shard_of_10000_channels(mh, rank):
     assert torch.equal(e.ch_bits, m.bits) and torch.equal(e.enc, m.enc) and torch.equal(e.peak, m.peak)
     assert int(m.post_hist.sum()) == plan.window_samples
     c = 2 ** h
-    vin, vout = cs.data[:C * T].view(C, T), out[:C * T].view(C, T)
+    vin, vout = cs.matrix(), cs.matrix(out)
     assert torch.equal(torch.clamp(vin[:, c:], max=S - 1), vout[:, c:])
     assert int(vout[:, :c].sum()) == 0
     # the histogram of the decoded stream, rank-mapped, prices to the same bits

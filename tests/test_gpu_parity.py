@@ -308,10 +308,10 @@ def test_full_size_properties(mh, S, h, K_rows):
     assert torch.equal(e.enc, m.enc) and torch.equal(e.peak, m.peak)
     assert int(m.post_hist.sum()) == plan.window_samples
     c = 2 ** h
-    view_in = cs.data[:C * T].view(C, T)[:, c:]
-    view_out = out[:C * T].view(C, T)[:, c:]
+    view_in = cs.matrix()[:, c:]
+    view_out = cs.matrix(out)[:, c:]
     assert torch.equal(torch.clamp(view_in, max=S - 1), view_out)
-    assert int(out[:C * T].view(C, T)[:, :c].sum()) == 0
+    assert int(cs.matrix(out)[:, :c].sum()) == 0
     # histogram of the decoded stream, rank-mapped, reproduces the measured histogram
     sums = torch.stack([(view_out == s).sum(1) for s in range(S)], 1)  # [C,S] by symbol
     assert int(sums.sum()) == plan.window_samples
@@ -488,6 +488,41 @@ def test_head_segments_of_format_revision_3_vs_oracle(mh, S, h, window):
             o = int(cs.ch_off[ch])
             assert np.array_equal(got[o + w0:o + w1], np.minimum(x[w0:w1], S - 1)), ch
             assert np.all(got[o:o + w0] == 0xEE) and np.all(got[o + w1:o + len(x)] == 0xEE), ch
+        plan.close()
+
+
+def test_head_segments_in_a_wave_task_plan_vs_oracle(mh):
+    """Channels just long enough for head segments but with few segments each: the planner picks wave tasks (one wave
+    per segment of any channel), so every head segment is a wave task of its own -- byte-exact against the oracle,
+    calibrating and preset encodes, and the strided matrix view of the (128-byte pitched) channel set."""
+    rng = np.random.RandomState(123)
+    T = 16 * mh.CHUNK + 64 + 100
+    chans = _channels(rng, [T] * 48, 0.2, 3.0)
+    cs = _cs(mh, chans)
+    assert int(cs.ch_off[1]) % 128 == 0 and int(cs.ch_off[1]) != T      # pitched rows
+    host = cs.data.cpu().numpy()
+    for S in (3, 8):
+        tab = helpers.sclv_tables()[S]
+        plan = mh.codec.Plan(cs.ch_off, cs.ch_len, S, 6, 1, mh.WIN_AFTER_CAL, tab, seg_chunks=2)
+        p = OC.Params(S, 6, 1, OC.WIN_AFTER_CAL, tab, seg_chunks=2)
+        seg = plan.segments()
+        assert int((seg["n"] == 64).sum()) == 48                          # one head segment per channel
+        e, oe = plan.encode(cs.data), OC.encode(host, cs.ch_off, cs.ch_len, p, nthreads=8)
+        for k in ("ch", "first", "n", "off"):
+            assert np.array_equal(seg[k], oe["seg"][k]), k
+        sw = e.seg_words.cpu().numpy().astype(np.uint64)[:plan.n_segments]
+        assert np.array_equal(sw, oe["seg_words"]) and np.array_equal(e.ch_bits.cpu().numpy().astype(np.uint64), oe["ch_bits"])
+        pay = e.payload.cpu().numpy().view(np.uint32)
+        for sidx in range(plan.n_segments):
+            o, n = int(seg["off"][sidx]), int(sw[sidx])
+            assert np.array_equal(pay[o:o + n], oe["payload"][o:o + n]), "segment %d" % sidx
+        e2 = plan.encode(cs.data, preset=(e.peak, e.enc))                  # preset encode: the same stream
+        assert torch.equal(e2.seg_words[:plan.n_segments], e.seg_words[:plan.n_segments]) and torch.equal(e2.ch_bits, e.ch_bits)
+        out = torch.full_like(cs.data, 0xEE)
+        plan.decode(e2, out)
+        assert plan.decode_ok()
+        assert torch.equal(cs.matrix(out)[:, 64:], torch.clamp(cs.matrix()[:, 64:], max=S - 1))
+        assert bool((cs.matrix(out)[:, :64] == 0xEE).all())
         plan.close()
 
 

@@ -41,7 +41,7 @@ for S in [int(s) for s in os.environ.get("SS", "2,3,4,5,6,8,10").split(",")]:
         e = timed(lambda: plan.encode(cs.data, out=enc))
         d = timed(lambda: plan.decode(enc, out))
         b = float(enc.ch_bits.sum()) / plan.window_samples
-        ok = torch.equal(torch.clamp(cs.data[:C * T].view(C, T)[:, 64:], max=S - 1), out[:C * T].view(C, T)[:, 64:])
+        ok = torch.equal(torch.clamp(cs.matrix()[:, 64:], max=S - 1), cs.matrix(out)[:, 64:])
         line += "  encode %.3f ms  decode %.3f ms  bits/sample %.3f  roundtrip %s" % (e, d, b, ok)
         plan.close()
         del enc, out

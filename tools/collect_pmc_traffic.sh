@@ -2,11 +2,11 @@
 # HBM traffic and SQ/LDS/TCP counters of the bench kernels: separate --pmc passes (never combined with
 # tracing), each of `python3 bench.py --steps 3 --warmup 1` without the extras.
 # usage: tools/collect_pmc_traffic.sh <tag>     -> gpurun_out/<tag>_pmc_*.csv, gpurun_out/<tag>_pmc_traffic.json
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-gather --no-per-S --no-small-shape"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-gather --no-per-S --no-small-shape --no-configs3"
 pass() {  # name, counters...
     local name=$1; shift
     rm -rf $R/gpurun_out/pmc_$name

@@ -3,7 +3,7 @@
 # the same command, the PMC passes, the auxiliary benches.  usage: bash tools/collect_round.sh <tag>
 # Outputs: gpurun_out/<tag>_*  (copy what is to be judged into profiles/).  Stops at the first failing step.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O
@@ -20,7 +20,7 @@ timeout -k 10 300 python tools/ablate_encode.py 2>&1 | grep -v amdgpu.ids > $O/$
 cat $O/${TAG}_bench_small.txt $O/${TAG}_bench_stream.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${TAG}_prof $O/${TAG}_prof_stream
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof.err
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 $R/bench.py --no-cpu-baseline --no-configs3 > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof.err
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stream -- python3 $R/tools/bench_stream.py > $O/${TAG}_prof_stream.log 2>&1
 cd $R
 find $O/${TAG}_prof -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
