@@ -1094,7 +1094,11 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
                     const uint32_t e = *reinterpret_cast<lds_u1 *>(off + tbase);
                     w |= (e & 0xFFFFu) << (8 * K * i);
                     adv = HY ? (e >> 16) & 0x7FFFu : e >> 16;
+#ifdef MH_HY_NEVER  // timing-only A/B build: what the decoders would cost if no entry were ever flagged (wrong output)
+                    if (false) {
+#else
                     if (HY && (int32_t)e < 0) {  // rare: second codeword reaches past the index bits
+#endif
                         bp += adv;
                         if (bp >= 32) {
                             buf = (buf >> 32) | ((uint64_t)nxt << 32);
