@@ -977,7 +977,7 @@ struct Dec2Args {
 // 1 for the pair table) + the 512-byte per-symbol table used by partial / oversize chunks
 __host__ __device__ inline uint32_t dec2_shared_dwords(uint32_t W, uint32_t K)
 {
-    return ((K == 4 ? 2u : 1u) << W) + kDtab / 4;
+    return (K == 1 ? 0u : (K == 4 ? 2u : 1u) << W) + kDtab / 4;  // K = 1: the per-symbol table is all there is
 }
 
 // staging dwords per wave: whole 16-byte-per-lane vectors (1 KiB each) covering NR * 64 words
@@ -1034,6 +1034,7 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
     //   needs bp + SH + W <= 64 and advances <= W, the flagged branch tops up first and advances
     //   <= 9, so bp stays below 56 and one top-up always restores bp < 32.
     static_assert(!HY || (K == 2 && RL != 1), "hybrid entries exist for the pair table only");
+    static_assert(K != 1 || RL != 1, "the one-symbol decoder tops its window up (RL 0 or 2)");
     // Pre-scaled index: the window is kept SH bits "early" (bp = stream position - SH, counted
     //   from the word before the staged payload), so (window >> bp) & (mask << SH) is already the
     //   byte offset of the table entry -- no shift in the lookup's dependent chain.  The table
@@ -1042,7 +1043,7 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
     //   last of the 4 lookups between reloads may start at window bit 55 and needs 8 more, which
     //   leaves no room for scale bits.
     constexpr bool kReload = RL == 1;
-    constexpr uint32_t SH = K == 4 ? 0 : 2;  // log2(bytes per pair-table entry)
+    constexpr uint32_t SH = K == 2 ? 2 : 0;  // log2(bytes per pair-table entry); K = 1 and K = 4 index unscaled
     typedef const __attribute__((address_space(3))) uint32_t lds_u1;
     const uint32_t maskS = maskW << SH;
     stage -= 1;
@@ -1086,7 +1087,11 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
             for (int i = 0; i < 4 / K; ++i) {
                 const uint32_t off = (uint32_t)(buf >> bp) & maskS;
                 uint32_t adv;
-                if (K == 4) {
+                if (K == 1) {  // one symbol per lookup from the 2^maxlen-entry byte table: no flagged entries, no branch
+                    const uint32_t e1 = tab1[(uint32_t)(buf >> bp) & mask1];
+                    w |= (e1 & 15u) << (8 * i);
+                    adv = e1 >> 4;
+                } else if (K == 4) {
                     const uint2 e = reinterpret_cast<const uint2 *>(tabw)[off];
                     w = e.x;
                     adv = e.y;
@@ -1159,6 +1164,78 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
     } else {
 #pragma unroll
         for (int k = 0; k < kRows; ++k) row(k);
+    }
+}
+
+// TWO full chunks of one segment decoded side by side by the ONE-SYMBOL decoder (K = 1).  With long codes the symbol
+// loop is a dependent chain per lane -- index from the window, LDS lookup, advance -- whose round trip nothing in the
+// lane can hide; the hybrid pair table halves the chain only on paper, because SOME lane of the wave meets a flagged
+// entry in 50-85 % of the lookups and the whole wave then runs the second, dependent lookup (profiles/
+// r03_hybrid_flag_upper_bound.txt).  The one-symbol table has no flagged entries and no branch in its loop, so two
+// independent chains -- the same lane's sub-streams in two chunks -- interleave perfectly: their lookups are issued back
+// to back and each LDS round trip serves both.  (The same pairing around the hybrid loop was slower: its branches cut
+// the two chains into separate basic blocks, r03_pair_decoding_ab.txt.)
+template <int M, int RL>
+__device__ __forceinline__ void decode_staged_pair1(ChunkHdr hA, ChunkHdr hB, const uint8_t *tab1, uint32_t mask1,
+                                                    const uint32_t *stageA, const uint32_t *stageB,
+                                                    uint8_t *__restrict__ outA, uint8_t *__restrict__ outB, int lane)
+{
+    static_assert(RL != 1, "top-up window (RL 0 or 2)");
+    struct Chain {
+        const uint32_t *stage;
+        uint64_t buf;
+        uint32_t wi, bp, nxt;
+    } A, B;
+    auto start = [&](Chain &c, const uint32_t *stage, uint32_t P) {
+        c.stage = stage - 1;  // (bit positions count from the word before the staged payload, as in decode_staged_chunk)
+        const uint32_t pos = P + 32;
+        c.wi = pos >> 5;
+        c.bp = pos & 31;
+        c.buf = (uint64_t)c.stage[c.wi] | ((uint64_t)c.stage[c.wi + 1] << 32);
+        c.nxt = c.stage[c.wi + 2];
+    };
+    start(A, stageA, hA.P);
+    start(B, stageB, hB.P);
+    auto top_up = [&](Chain &c) {
+        if (RL == 2) {
+            const bool t = c.bp >= 32;
+            const uint32_t lo = t ? (uint32_t)(c.buf >> 32) : (uint32_t)c.buf;
+            const uint32_t hi = t ? c.nxt : (uint32_t)(c.buf >> 32);
+            c.buf = (uint64_t)lo | ((uint64_t)hi << 32);
+            c.bp &= 31;
+            c.wi += t ? 1u : 0u;
+            c.nxt = c.stage[c.wi + 2];
+        } else if (c.bp >= 32) {
+            c.buf = (c.buf >> 32) | ((uint64_t)c.nxt << 32);
+            c.bp -= 32;
+            ++c.wi;
+            c.nxt = c.stage[c.wi + 2];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) {
+        u32x4 oA, oB;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t wA = 0, wB = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t eA = tab1[(uint32_t)(A.buf >> A.bp) & mask1];  // both lookups in flight together
+                const uint32_t eB = tab1[(uint32_t)(B.buf >> B.bp) & mask1];
+                wA |= (eA & 15u) << (8 * i);
+                wB |= (eB & 15u) << (8 * i);
+                A.bp += eA >> 4;
+                B.bp += eB >> 4;
+                if ((d * 4 + i + 1) % M == 0) {
+                    top_up(A);
+                    top_up(B);
+                }
+            }
+            oA[d] = wA;
+            oB[d] = wB;
+        }
+        __builtin_nontemporal_store(oA, reinterpret_cast<u32x4_u *>(outA + ((uint32_t)k * kLanes + lane) * MH_PIECE));
+        __builtin_nontemporal_store(oB, reinterpret_cast<u32x4_u *>(outB + ((uint32_t)k * kLanes + lane) * MH_PIECE));
     }
 }
 
@@ -1364,6 +1441,72 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
 #undef MH_DEC_BAIL
 }
 
+// One-symbol decoders: the full chunks of a segment two at a time (decode_staged_pair1).  Both headers are scanned
+// first (the second one's position follows from the first), then ONE batch of loads brings payload A, header B and
+// payload B -- contiguous in the stream -- into the wave's staging area, and the two chunks decode side by side.
+// Whatever does not fit that scheme goes through decode_segment: a pair too large for the staging area, the odd full
+// chunk, the partial chunk.  Same bounds rules: every header-steered read is checked against lim first.
+template <int K, int M, int NR, int RL, bool HY>
+__device__ __forceinline__ void decode_segment_dual(const DecArgs &d, uint64_t pos, uint8_t *__restrict__ out, uint64_t n,
+                                                    const uint32_t *tab, uint32_t tbase, uint32_t maskW, const uint8_t *tab1,
+                                                    uint32_t mask1, uint32_t *stage, int lane)
+{
+    static_assert(K == 1 && !HY, "pairing is for the branch-free one-symbol loop");
+    constexpr uint32_t kCap = NR * 64;
+    constexpr int NV = (NR + 3) / 4;
+    constexpr uint32_t kMinFull = kChunk / 32;
+    const uint64_t lim = d.payload_words;
+    auto room = [&](uint64_t at, uint64_t need) { return at <= lim && lim - at >= need; };
+    const uint32_t nfull = (uint32_t)(n / kChunk);
+    uint32_t c = 0;
+    while (c + 2 <= nfull) {
+        if (!room(pos, 32)) {
+            if (lane == 0) atomicMax(d.err, d.epoch);
+            return;
+        }
+        const uint32_t *in = d.payload + pos;
+        const ChunkHdr hA = scan_header(in[lane & 31], lane);
+        // header A, payload A and the first 32 words of chunk B (a full chunk is longer than that) must be there
+        if (hA.nw < kMinFull || !room(pos, (uint64_t)hA.hw + hA.nw + 32)) {
+            if (lane == 0) atomicMax(d.err, d.epoch);
+            return;
+        }
+        const uint32_t *payA = in + hA.hw;
+        const ChunkHdr hB = scan_header(payA[hA.nw + (uint32_t)(lane & 31)], lane);
+        const uint64_t posB = pos + hA.hw + hA.nw;
+        if (hB.nw < kMinFull || !room(posB, (uint64_t)hB.hw + hB.nw + 3)) {
+            if (lane == 0) atomicMax(d.err, d.epoch);
+            return;
+        }
+        const uint32_t total = hA.nw + hB.hw + hB.nw + 3;  // payload A, chunk B, 3 words of read-ahead
+        if (total > kCap) break;  // (too many bits per sample in both chunks for the staging area: one at a time below)
+        u32x4 R[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {  // fixed instruction count; lanes past the end re-read the last vector
+            uint32_t i_ = (uint32_t)(j * 256 + lane * 4);
+            i_ = i_ + 4 <= total ? i_ : total - 4;
+            R[j] = *reinterpret_cast<const u32x4_u *>(payA + i_);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            uint32_t i_ = (uint32_t)(j * 256 + lane * 4);
+            i_ = i_ + 4 <= total ? i_ : total - 4;
+            *reinterpret_cast<u32x4_u *>(stage + i_) = R[j];  // (clamped lanes rewrite the last vector with the same values)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        decode_staged_pair1<M, RL>(hA, hB, tab1, mask1, stage, stage + hA.nw + hB.hw, out + (size_t)c * kChunk,
+                                   out + (size_t)(c + 1) * kChunk, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        pos = posB + hB.hw + hB.nw;
+        c += 2;
+    }
+    if ((uint64_t)c * kChunk < n)
+        decode_segment<K, M, NR, RL, HY>(d, pos, out + (size_t)c * kChunk, n - (uint64_t)c * kChunk, tab, tbase, maskW, tab1, mask1,
+                                         stage, lane);
+}
+
 // NR payload registers per lane: the next chunk's payload (up to NR*64 words) is fetched into
 // registers while the current chunk decodes, and lands in LDS at the top of the next iteration.
 // All those loads are issued BEFORE the current chunk's 16 output stores, so waiting for them
@@ -1445,7 +1588,7 @@ __device__ __forceinline__ uint32_t build_decode_tables(const Dec2Args &a, uint3
             }
             reinterpret_cast<uint2 *>(tab)[idx] = make_uint2(bytes, bpos);
         }
-    } else {
+    } else if (K == 2) {
         table_sync<NT>();
         for (uint32_t idx = (uint32_t)t; idx < (1u << W); idx += NT) {
             const uint32_t e1 = tab1[idx & mask1];
@@ -1460,7 +1603,7 @@ __device__ __forceinline__ uint32_t build_decode_tables(const Dec2Args &a, uint3
     return mask1;
 }
 
-template <int K, int M, int NR, int RL, bool HY>
+template <int K, int M, int NR, int RL, bool HY, bool DUAL = false>
 __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -1475,21 +1618,25 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2(Dec2Args a)
     const uint32_t W = a.W;
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;  // dwords per table entry
     uint32_t *tab = smem;
-    uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (kEntDw << W));
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(smem + (K == 1 ? 0u : kEntDw << W));
     // tables built by the workgroup itself from the channel's (peak, encoder) word: no table kernel in front of
     // the decoder, no per-channel tables in global memory
     const uint32_t mask1 = build_decode_tables<K, 256>(a, ch, tab, tab1, (int)threadIdx.x, lane);
     if ((uint32_t)wave >= nseg) return;
     uint32_t *stage = smem + dec2_shared_dwords(W, K) + (size_t)wave * dec2_stage_dwords(NR);
     const uint32_t seg = seg0 + (uint32_t)wave;
-    decode_segment<K, M, NR, RL, HY>(a.d, a.d.seg_off[seg], a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg],
-                                     a.d.seg_n[seg], tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
+    if constexpr (DUAL)
+        decode_segment_dual<K, M, NR, RL, HY>(a.d, a.d.seg_off[seg], a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg],
+                                              a.d.seg_n[seg], tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
+    else
+        decode_segment<K, M, NR, RL, HY>(a.d, a.d.seg_off[seg], a.d.out + a.d.ch_off[ch] + a.d.w0[ch] + a.d.seg_first[seg],
+                                         a.d.seg_n[seg], tab, 0u, (1u << W) - 1u, tab1, mask1, stage, lane);
 }
 
 // Short channels: one WAVE per segment of any channel, tables per wave (see k_encode2w).  The wave
 // derives its tables from the channel's (peak, encoder) word and the plan's codebooks itself, so
 // this decode is ONE launch: no table kernel in front of it.
-template <int K, int M, int NR, int RL, bool HY>
+template <int K, int M, int NR, int RL, bool HY, bool DUAL = false>
 __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -1501,13 +1648,17 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
     constexpr uint32_t kEntDw = K == 4 ? 2 : 1;
     const uint32_t wdw = dec2_shared_dwords(W, K) + dec2_stage_dwords(NR);  // dwords per wave
     uint32_t *tab = smem + (size_t)wave * wdw;
-    uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (kEntDw << W));
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(tab + (K == 1 ? 0u : kEntDw << W));
     const uint64_t pos = a.plan_slots ? t.dst_off : a.d.seg_off[t.seg];
     // a (peak, encoder) word outside the plan's ranges (corrupt metadata) decodes as (0, 0)
     const uint32_t mask1 = build_decode_tables<K, 64>(a, t.ch, tab, tab1, lane, lane);
     const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tab;
-    decode_segment<K, M, NR, RL, HY>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
-                                     tab + dec2_shared_dwords(W, K), lane);
+    if constexpr (DUAL)
+        decode_segment_dual<K, M, NR, RL, HY>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
+                                              tab + dec2_shared_dwords(W, K), lane);
+    else
+        decode_segment<K, M, NR, RL, HY>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
+                                         tab + dec2_shared_dwords(W, K), lane);
 }
 
 // ------------------------------------------------------------------------------------------

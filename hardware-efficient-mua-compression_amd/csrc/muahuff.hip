@@ -243,12 +243,12 @@ static int launch_encode2w(const mh::Enc2Args &a, hipStream_t st)
 constexpr size_t kDecK4LdsFloor = MH_DEC_K4_LDS_FLOOR;  // 3 workgroups per CU (see launch_decode2)
 
 
-template <int K, int M, int NR, int RL, bool HY>
+template <int K, int M, int NR, int RL, bool HY, bool DUAL = false>
 static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st)
 {
     if (wave_tasks) {
         const size_t lds = 4 * ((size_t)mh::dec2_shared_dwords(a.W, K) + mh::dec2_stage_dwords(NR)) * sizeof(uint32_t);
-        auto kern = mh::k_decode2w<K, M, NR, RL, HY>;
+        auto kern = mh::k_decode2w<K, M, NR, RL, HY, DUAL>;
         if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, false);
         hipLaunchKernelGGL(kern, dim3((a.t.ntask + 3) / 4), dim3(256), lds, st, a);
     } else {
@@ -263,7 +263,7 @@ static int launch_decode2(const mh::Dec2Args &a, bool wave_tasks, hipStream_t st
 #ifdef MH_TUNING
         if (const char *e = getenv("MH_DEC_LDS_MIN")) lds = (size_t)atoi(e) > lds_need ? (size_t)atoi(e) : lds_need;
 #endif
-        auto kern = mh::k_decode2<K, M, NR, RL, HY>;
+        auto kern = mh::k_decode2<K, M, NR, RL, HY, DUAL>;
         if (g_prepare_only) return prepare_kernel(reinterpret_cast<const void *>(kern), lds, K == 2);
         hipLaunchKernelGGL(kern, dim3(a.t.ntask), dim3(256), lds, st, a);
     }
@@ -386,6 +386,19 @@ static int dispatch_decode(const mh_plan *p, const mh::Dec2Args &a2, hipStream_t
     if (L <= 2) return launch_decode2<4, 4, 17, 1, false>(a2, wt, st);  // worst-case chunk = 1027 words: never oversize
     if (L == 3) return launch_decode2<2, 2, 25, 2, false>(a2, wt, st);
     if (a2.W >= 2 * L) return launch_decode2<2, 2, 32, 0, false>(a2, wt, st);
+#ifndef MH_DEC_K1
+#define MH_DEC_K1 1  // A/B builds: 0 = never, 1 = wave-task plans, 2 = every plan whose pair table would be hybrid
+#endif
+#ifndef MH_DEC_K1_NR
+#define MH_DEC_K1_NR 36
+#endif
+    // Long codes on SHORT channels (wave tasks, where every wave builds its own tables): the one-symbol decoder -- a
+    // 2^maxlen-byte table instead of a 256-entry hybrid pair table whose flagged entries make almost every lookup of
+    // the wave take the slow path (8 index bits) -- with the two chunks of a segment side by side (decode_staged_pair1).
+    // 10 000 x 20 000: decode S=8 82 -> 74 us, S=10 92 -> 77 us; 2400 x 72 000: 70 -> 68 us.  On long channels (shared
+    // 1024-entry tables) it loses: S=8 2.35 -> 2.82 ms -- twice the LDS lookups, and those decoders are bound by LDS
+    // bank-conflict throughput, not by the latency of the chain (profiles/r03_k1_pair_decoding_ab.txt).
+    if ((MH_DEC_K1 >= 2 || (MH_DEC_K1 == 1 && wt)) && a2.W < 2 * L) return launch_decode2<1, 2, MH_DEC_K1_NR, 2, false, true>(a2, wt, st);
     // hybrid pair table: W < 2 * maxlen index bits, one-symbol entries flagged
     if (p->h.dec_NR == 31) return launch_decode2<2, 2, 31, 2, true>(a2, wt, st);
     return launch_decode2<2, 2, 32, 0, true>(a2, wt, st);
