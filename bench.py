@@ -331,6 +331,28 @@ def configs3_block(a, rank, world, dist, coll_dev, tab):
     return res
 
 
+def configs3_guarded(a, rank, world, dist, coll_dev, tab, local, deadline):
+    """configs3_block in a helper thread under a deadline: the extra block can never cost the run its headline line (an
+    allocation failure or a stuck collective becomes {"error": ...}) -- but it does cost the exit status.
+    -> (block or error dict, stuck?)"""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            torch.cuda.set_device(local)
+            box["v"] = configs3_block(a, rank, world, dist, coll_dev, tab)
+        except Exception as e:  # noqa: BLE001 -- reported in the line
+            box["v"] = {"error": repr(e)}
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(deadline)
+    if th.is_alive():
+        return {"error": "configs3 block did not finish within %ds" % deadline}, True
+    return box["v"], False
+
+
 # ---- one rank ------------------------------------------------------------------------------------
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -533,7 +555,11 @@ def main(argv=None):
         plan.close()
         del cs, enc, out, plan
         torch.cuda.empty_cache()
-        c3 = configs3_block(a, rank, world, dist, coll_dev, tab)
+        c3, c3_stuck = configs3_guarded(a, rank, world, dist, coll_dev, tab, local, a.gather_deadline)
+        if c3_stuck:
+            rc = RC_GATHER_STUCK
+        elif "error" in c3:
+            rc = rc or RC_GATHER_FAILED
 
     if rank == 0:
         total_samples = samples * world
@@ -620,7 +646,11 @@ def main(argv=None):
             plan.close()
             del cs, enc, out, plan
             torch.cuda.empty_cache()
-            line["configs3"] = configs3_block(a, rank, world, None, coll_dev, tab)
+            line["configs3"], c3_stuck = configs3_guarded(a, rank, world, None, coll_dev, tab, local, a.gather_deadline)
+            if c3_stuck:
+                rc = RC_GATHER_STUCK
+            elif "error" in line["configs3"]:
+                rc = rc or RC_GATHER_FAILED
         print(json.dumps(line), flush=True)
     sys.stdout.flush()
     if rc == RC_GATHER_STUCK:
