@@ -660,8 +660,8 @@ def test_packed_plans_refuse_decode(mh):
 
 
 def test_randomised_design_points_vs_oracle(mh):
-    """60 random (S, h, mapper, window, K subset, seg_chunks, ragged lengths, byte offsets):
-    measure / encode / decode byte-exact against the CPU oracle."""
+    """60 random (S, h, mapper, window, K subset, seg_chunks, ragged lengths, byte offsets; every fourth with channels
+    of 8 .. 33 chunks: shared-table tasks, head segments): measure / encode / decode byte-exact against the CPU oracle."""
     import os
     # MH_FUZZ_SEED / MH_FUZZ_ITERS: longer one-off campaigns (the committed default is what CI runs)
     rng = np.random.RandomState(int(os.environ.get("MH_FUZZ_SEED", "20261004")))
@@ -677,6 +677,10 @@ def test_randomised_design_points_vs_oracle(mh):
         nch = int(rng.randint(1, 7))
         lens = [int(rng.choice([1, 2, 17, 100, 4095, 16384, 16400, 33000, 50000, 70000])) + int(rng.randint(0, 40))
                 for _ in range(nch)]
+        if it % 4 == 1:  # long channels: workgroup tasks of 4 segments (shared tables), head segments from 16 chunks on
+            nch = int(rng.randint(1, 4))
+            lens = [int(rng.choice([131072, 200000, 262144, 262144 + 4096, 300000, 540000])) + int(rng.randint(0, 200))
+                    for _ in range(nch)]
         chans = [np.minimum(rng.poisson(float(np.exp(rng.uniform(-3, 2.3))), size=T), 255).astype(np.uint8) for T in lens]
         if it % 3 == 2:  # runs of large counts: long codewords back to back (decoder flag / encoder escape paths)
             for x in chans:
