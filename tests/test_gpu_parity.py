@@ -607,6 +607,29 @@ def test_fused_measure_at_its_limits(mh):
         plan.close()
 
 
+def test_placement_probed_buffers_are_ordinary_buffers(mh):
+    """Plan.alloc_encoded_probed / alloc_output_probed pick a buffer among candidates by timing the real op (the part
+    runs the same kernel at one of two levels depending on which physical pages hold its buffers); what they return is
+    an ordinary Encoded / output tensor: the winner holds a valid stream and decodes exactly."""
+    rng = np.random.RandomState(9)
+    chans = _channels(rng, [200000, 70001, 16384 * 3], 0.2, 3.0)
+    cs = _cs(mh, chans)
+    plan = mh.codec.Plan(cs.ch_off, cs.ch_len, 3, 6, 1, mh.WIN_AFTER_CAL, helpers.sclv_tables()[3])
+    ref = plan.encode(cs.data)
+    enc, ms = plan.alloc_encoded_probed(cs.data, tries=3, reps=2)
+    assert len(ms) == 3 and all(m > 0 for m in ms)
+    assert torch.equal(enc.ch_bits, ref.ch_bits) and torch.equal(enc.seg_words, ref.seg_words)
+    out, ms2 = plan.alloc_output_probed(enc, cs.data, tries=2, reps=2)
+    assert len(ms2) == 2 and out.shape == cs.data.shape
+    out.fill_(0xEE)
+    plan.decode(enc, out)
+    got = out.cpu().numpy()
+    for c, x in enumerate(chans):
+        o = int(cs.ch_off[c])
+        assert np.array_equal(got[o + 64:o + len(x)], np.minimum(x[64:], 2))
+    plan.close()
+
+
 def test_decode_status_is_sticky_across_graph_replays_and_direct_calls(mh):
     """A captured decode carries no per-call state, so the status word is a sticky flag: a corrupt stream that
     goes through a REPLAYED graph is reported even when direct decodes on the same plan happened after the
