@@ -225,7 +225,9 @@ static int launch_encode2(const mh::Enc2Args &a, hipStream_t st)
     // 2.02-2.16 -> 1.975 ms with placement-probed payload buffers, and no longer sensitive to where the input sits
     // (profiles/r03_occupancy_ab.txt).  The longer-code encoders are compute-bound before their stores and lose
     // (S = 8: +4 %), S = 4..6 are indifferent (-0.8 %): only LC = 0 is capped, through the LDS request.
-    if (LC == 0 && PK == 0 && ABL == 0 && lds < kDecK4LdsFloor) lds = kDecK4LdsFloor;
+    // Only where the launch has many rounds of workgroups: with 2640 tasks (96 ch x 3.6e6 bins) a quarter fewer slots cost
+    // a whole extra round (77.7 -> 80.2 us).
+    if (LC == 0 && PK == 0 && ABL == 0 && a.t.ntask >= 16384 && lds < kDecK4LdsFloor) lds = kDecK4LdsFloor;
 #ifdef MH_TUNING  // occupancy cap through the LDS request (A/B runs)
     if (const char *e = getenv("MH_ENC_LDS_MIN")) {  // replaces the floor above
         const size_t need = 4 * (size_t)mh::enc2_wave_dwords(a.e.stage_dw) * sizeof(uint32_t);
