@@ -637,8 +637,8 @@ def main(argv=None):
                            "measure_GBps": meas_samples / meas_ms / 1e6,
                            "measure_window": "[c, c+T/2) reference rule, bits/sample %.4f" % ref_bits_per_sample},
             "roofline": roof,
-            "placement": {"what": "payload and output buffers of the timed region chosen among candidates alive at the same "
-                                  "time by the median of 4 launches of the real op (setup, untimed); ms per candidate",
+            "placement": {"what": "input copy, payload and output buffer of the timed region chosen among candidates alive at "
+                                  "the same time by the median of 4 launches of the real op (setup, untimed); ms per candidate",
                           "encode_ms_per_input_and_payload_candidate": place_enc, "decode_ms_per_output_candidate": place_dec},
             "device": info["name"] + " " + info["arch"],
         }
