@@ -224,6 +224,22 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
     out = torch.empty_like(cs.data)
     e_ms = event_times(lambda: plan.encode(cs.data, out=enc), reps, warm=3)
     d_ms = event_times(lambda: plan.decode(enc, out), reps, warm=3)
+
+    def back_to_back(f, n=50):
+        """ms per op of n launches of the same op between ONE pair of events: the way a pipeline over many
+        recordings runs them.  (An event pair around a single launch also times the idle queue's start-up: an EMPTY
+        kernel reads 5.8 us that way and 1.5 us back to back -- tools/enc_probe, profiles/r03_short_channels.txt.)"""
+        f()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        for _ in range(n):
+            f()
+        b_.record()
+        torch.cuda.synchronize()
+        return a_.elapsed_time(b_) / n
+
+    e_bb = back_to_back(lambda: plan.encode(cs.data, out=enc))
+    d_bb = back_to_back(lambda: plan.decode(enc, out))
     # the reference's own computation on this shape (calibrate + window histogram + bits, its [c, c+T/2) window)
     plan_m = codec.Plan(cs.ch_off, cs.ch_len, S, h, mode, muahuff.WIN_REF_HALF, tab)
     m_out = plan_m.measure(cs.data)
@@ -243,6 +259,8 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
     enc10 = plan10.alloc_encoded()
     e10 = float(np.median(event_times(lambda: plan10.encode(cs.data, out=enc10), reps, warm=3)))
     d10 = float(np.median(event_times(lambda: plan10.decode(enc10, out), reps, warm=3)))
+    e10_bb = back_to_back(lambda: plan10.encode(cs.data, out=enc10))
+    d10_bb = back_to_back(lambda: plan10.decode(enc10, out))
     b10 = float(enc10.ch_bits.sum().item()) / n
     ab10 = n * (1.0 + b10 / 8.0)
     plan10.close()
@@ -252,14 +270,21 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
     pm10.close()
     s10 = {"S": S10, "K": int(tab10.shape[0]), "bits_per_sample": b10, "encode_us": e10 * 1e3, "decode_us": d10 * 1e3,
            "encode_frac": ab10 / e10 / 1e6 / HBM_PEAK_GBS, "decode_frac": ab10 / d10 / 1e6 / HBM_PEAK_GBS,
-           "measure_us": m10 * 1e3, "measure_frac": m_n / m10 / 1e6 / HBM_PEAK_GBS}
+           "measure_us": m10 * 1e3, "measure_frac": m_n / m10 / 1e6 / HBM_PEAK_GBS,
+           "back_to_back": {"encode_us": e10_bb * 1e3, "decode_us": d10_bb * 1e3,
+                            "encode_frac": ab10 / e10_bb / 1e6 / HBM_PEAK_GBS, "decode_frac": ab10 / d10_bb / 1e6 / HBM_PEAK_GBS}}
     return {"workload": "2400 channels x 72 000 bins (50 ms bins), S=%d, 2^%d calibration" % (S, h),
             "samples": n, "bits_per_sample": b, "encode_us": em * 1e3, "decode_us": dm * 1e3,
             "encode_GBps": ab / em / 1e6, "decode_GBps": ab / dm / 1e6,
             "encode_frac": ab / em / 1e6 / HBM_PEAK_GBS, "decode_frac": ab / dm / 1e6 / HBM_PEAK_GBS,
             "measure_us": m_ms * 1e3, "measure_GBps": m_n / m_ms / 1e6, "measure_frac": m_n / m_ms / 1e6 / HBM_PEAK_GBS,
+            "back_to_back": {"encode_us": e_bb * 1e3, "decode_us": d_bb * 1e3,
+                             "encode_frac": ab / e_bb / 1e6 / HBM_PEAK_GBS, "decode_frac": ab / d_bb / 1e6 / HBM_PEAK_GBS,
+                             "what": "50 launches of the op between one pair of events / 50"},
             "S10": s10,
-            "timing": "HIP events around each op (calibrate/table kernel + codec kernel), median of %d" % reps}
+            "timing": "HIP events around each op (calibrate/table kernel + codec kernel), median of %d; an event pair "
+                      "around ONE launch includes the idle queue's start-up (an empty kernel reads 5.8 us that way, "
+                      "1.5 us back to back), hence the second set" % reps}
 
 
 def configs3_block(a, rank, world, dist, coll_dev, tab):

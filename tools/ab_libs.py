@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of two builds of libmuahuff.so: encode / decode of the roofline set (1024 channels x
 1e7 bins) per S and of the short-channel set, each library in its own child process, alternating.
-env: PROBE=1 (placement-probed payload / output buffers)  SS=3,5,8,10  REPS=2  RATES=lo,hi  H=6 (calibration bits: the window starts at sample 2^H)  SMALL_ONLY=1  BIG_ONLY=1
+env: PROBE=1 (placement-probed payload / output buffers)  SS=3,5,8,10  REPS=2  RATES=lo,hi  H=6 (calibration bits: the window starts at sample 2^H)  SMALL_ONLY=1  BIG_ONLY=1  SEG=0 (chunks per segment, 0 = the planner's choice)
 usage: ab_libs.py A.so B.so ...      (children: ab_libs.py --one X.so)"""
 import os
 import subprocess
@@ -40,7 +40,8 @@ def one(path):
         cs = synth.generate(C, T, seed=5, lo=lo, hi=hi)
         out = torch.empty_like(cs.data)
         for S in (Ss if T > 1_000_000 or os.environ.get("SMALL_ONLY") == "1" else Ss[:2]):
-            plan = codec.Plan(cs.ch_off, cs.ch_len, S, int(os.environ.get("H", "6")), 1, muahuff.WIN_AFTER_CAL, sclv.table(S))
+            plan = codec.Plan(cs.ch_off, cs.ch_len, S, int(os.environ.get("H", "6")), 1, muahuff.WIN_AFTER_CAL, sclv.table(S),
+                              seg_chunks=int(os.environ.get("SEG", "0")))
             # (buffers chosen by placement when PROBE=1: takes the part's two allocation-dependent levels out of an A/B)
             if os.environ.get("PROBE") == "1" and hasattr(plan, "alloc_encoded_probed"):
                 enc, _ = plan.alloc_encoded_probed(cs.data, tries=3, reps=3)
