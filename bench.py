@@ -225,18 +225,31 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
     e_ms = event_times(lambda: plan.encode(cs.data, out=enc), reps, warm=3)
     d_ms = event_times(lambda: plan.decode(enc, out), reps, warm=3)
 
+    side = torch.cuda.Stream()
+
     def back_to_back(f, n=50):
-        """ms per op of n launches of the same op between ONE pair of events: the way a pipeline over many
-        recordings runs them.  (An event pair around a single launch also times the idle queue's start-up: an EMPTY
-        kernel reads 5.8 us that way and 1.5 us back to back -- tools/enc_probe, profiles/r03_short_channels.txt.)"""
-        f()
-        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a_.record()
-        for _ in range(n):
+        """ms per op of n launches of the same op replayed as ONE hipGraph between one pair of events: the GPU-side
+        cost of the op in a pipeline over many recordings, free of the host's per-call time.  (An event pair around a
+        single launch also times the idle queue's start-up: an EMPTY kernel reads 5.8 us that way and 1.5 us back to
+        back -- tools/enc_probe, profiles/r03_short_channels.txt.)"""
+        with torch.cuda.stream(side):
             f()
-        b_.record()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(n):
+                    f()
+            g.replay()
+            ts = []
+            for _ in range(5):
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                g.replay()
+                b_.record()
+                b_.synchronize()
+                ts.append(a_.elapsed_time(b_) / n)
         torch.cuda.synchronize()
-        return a_.elapsed_time(b_) / n
+        del g
+        return float(np.median(ts))
 
     e_bb = back_to_back(lambda: plan.encode(cs.data, out=enc))
     d_bb = back_to_back(lambda: plan.decode(enc, out))
@@ -280,7 +293,7 @@ def small_shape(S, h, mode, seg_chunks, reps=20):
             "measure_us": m_ms * 1e3, "measure_GBps": m_n / m_ms / 1e6, "measure_frac": m_n / m_ms / 1e6 / HBM_PEAK_GBS,
             "back_to_back": {"encode_us": e_bb * 1e3, "decode_us": d_bb * 1e3,
                              "encode_frac": ab / e_bb / 1e6 / HBM_PEAK_GBS, "decode_frac": ab / d_bb / 1e6 / HBM_PEAK_GBS,
-                             "what": "50 launches of the op between one pair of events / 50"},
+                             "what": "50 launches of the op captured in one hipGraph, replayed between one pair of events / 50, median of 5"},
             "S10": s10,
             "timing": "HIP events around each op (calibrate/table kernel + codec kernel), median of %d; an event pair "
                       "around ONE launch includes the idle queue's start-up (an empty kernel reads 5.8 us that way, "
