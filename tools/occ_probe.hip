@@ -74,6 +74,43 @@ __global__ __launch_bounds__(256) void k_enc_mix(const uint8_t* __restrict__ src
     if (acc.x == 0x12345u) pad[0] = 1;
 }
 
+// encoder mix with the segment's output written in ONE burst at the end of the segment (wend = 1) instead of per chunk,
+// or in 256-byte pieces as they "fill" (wend = 2: one 256-B block per 1.4 rows, the codec's own cadence)
+__global__ __launch_bounds__(256) void k_enc_mix_w(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t chunks, uint32_t wout, size_t nseg, size_t slot, int wend)
+{
+    extern __shared__ uint32_t pad[];
+    const int lane = threadIdx.x & 63;
+    const size_t seg = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const uint8_t* p = src + seg * (size_t)chunks * 16384;
+    uint8_t* o = dst + seg * slot;
+    u32x4 acc = {0,0,0,0};
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load((const u32x4*)(p + (k*64+lane)*16));
+    uint32_t done = 0;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        const uint8_t* cur = p + (size_t)c*16384;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            acc ^= v[k&7];
+            if (k < 8 || c + 1 < chunks) v[k&7] = __builtin_nontemporal_load((const u32x4*)(cur + ((k+8)*64+lane)*16));
+            if (wend == 2) {  // 256-byte blocks as rows complete: 16 lanes x 16 bytes
+                const uint32_t upto = (uint32_t)(((uint64_t)(c * 16 + k + 1) * wout / 16) & ~255u);
+                for (; done < upto; done += 256)
+                    if (lane < 16) __builtin_nontemporal_store(acc, (u32x4*)(o + done + lane * 16));
+            }
+        }
+        if (wend == 0) {
+            for (uint32_t i = lane * 16; i < wout; i += 1024) __builtin_nontemporal_store(acc, (u32x4*)(o + i));
+            o += wout;
+        }
+    }
+    if (wend == 1)
+        for (uint32_t i = lane * 16; i < wout * chunks; i += 1024) __builtin_nontemporal_store(acc, (u32x4*)(o + i));
+    if (acc.x == 0x12345u) pad[0] = 1;
+}
+
 template <typename F> float timeit(F f, int reps = 5)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -132,6 +169,15 @@ int main()
             float d = timeit([&]{ hipLaunchKernelGGL(k_dec_mix<1>, dim3((nseg+3)/4 - 1), dim3(256), (size_t)41984, 0, small_, big + shift, chunks, 2944u, nseg - 4, slot); });
             printf("rows shifted by %zu bytes : encoder mix %.3f ms, decoder mix (3 workgroups/CU) %.3f ms\n", shift, e, d);
         }
+        // how the segment's output leaves: per chunk, one burst per segment, 256-byte blocks as they fill
+        for (uint32_t ch : {2u, 4u})
+            for (int wend : {0, 1, 2}) {
+                const size_t ns = bytes / ((size_t)ch * 16384), sl = (size_t)ch * 4224;
+                float e = timeit([&]{ hipLaunchKernelGGL(k_enc_mix_w, dim3((ns+3)/4), dim3(256), lds, 0, big, small_, ch, 2944u, ns, sl, wend); });
+                printf("encoder mix, %u chunks per segment, output %s : %.3f ms\n", ch,
+                       wend == 0 ? "per chunk" : wend == 1 ? "in one burst per segment" : "in 256-byte blocks as they fill", e);
+                fflush(stdout);
+            }
     }
     return 0;
 }
