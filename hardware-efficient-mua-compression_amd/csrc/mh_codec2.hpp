@@ -340,17 +340,20 @@ __device__ __forceinline__ uint32_t *stage_lane_base(uint32_t *buf, uint32_t cap
 // written with plain ds_write; only a sub-stream's first and last word, which it may share with its neighbours, are
 // OR-ed into words zeroed beforehand: 2 LDS atomics per sub-stream instead of up to 2 per staged dword (and no
 // zero-fill of the image).  Partial chunks (sub-streams of any length, several to a word) keep the OR for every dword.
-template <int NE, int ABL, bool FULL>
+// DPP: the wave-wide scan / min / max of the sub-stream lengths as DPP ladders instead of ds_bpermute chains (mh_device.hpp,
+// wave_scan_incl_dpp: for launches that wait on latency -- wave-task encoders, partial chunks).
+template <int NE, int ABL, bool FULL, bool DPP = false>
 __device__ __forceinline__ void merge_and_flush(uint32_t *buf, uint32_t cap, uint32_t tot, uint32_t sp,
                                                 uint32_t *__restrict__ &dst, uint32_t &pend, int lane,
                                                 uint32_t &words, uint32_t &bits)
 {
-    const uint32_t incl = wave_scan_incl(tot, lane);
+    const uint32_t incl = DPP ? wave_scan_incl_dpp(tot) : wave_scan_incl(tot, lane);
     const uint32_t P = incl - tot;
-    const uint32_t B = __shfl(incl, 63, 64);
+    const uint32_t B = DPP ? wave_last(incl) : __shfl(incl, 63, 64);
     const uint32_t nw = (B + 31) >> 5;
     uint32_t *hdr = buf + pend;
-    const uint32_t mn = wave_min(tot), hwid = hdr_width(wave_max(tot) - mn), hw = hdr_words(hwid);
+    const uint32_t mn = DPP ? wave_min_dpp(tot) : wave_min(tot);
+    const uint32_t hwid = hdr_width((DPP ? wave_max_dpp(tot) : wave_max(tot)) - mn), hw = hdr_words(hwid);
     uint32_t *pay = hdr + hw;  // hw <= 25 < kHdrWords: the image starts no higher than before
     if ((uint32_t)lane < hw) hdr[lane] = lane == 0 ? (mn | (hwid << 12)) : 0u;
     MH_WAVE_SYNC();
@@ -551,7 +554,7 @@ __device__ __forceinline__ void encode_row_packed(typename RawPiece<PK>::type r,
 // tightens by one per row down to vmcnt(0) -- the wave then drains its whole window at each chunk end.
 // nxt = first byte of the chunk that follows `cur` in the stream (cur + one chunk in the plain layouts,
 // elsewhere in the chunk-blocked intermediate of the time-major path); only read when HAS_NEXT
-template <int LC, int PB, int ABL, bool HAS_NEXT, int PK>
+template <int LC, int PB, int ABL, bool HAS_NEXT, int PK, bool DPP = false>
 __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&v)[kWin], const uint8_t *__restrict__ cur,
                                                   const uint8_t *__restrict__ nxt, const uint2 *lut2, const uint2 *lut1,
                                                   uint32_t *buf, uint32_t cap, uint32_t *__restrict__ &dst,
@@ -599,7 +602,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
         overflow_chunk<false, PK>(cur, kChunk, lut1, buf, dst, pend, lane, words, bits);
         return;
     }
-    merge_and_flush<stage_ne(LC), ABL, true>(buf, cap, tot, sp, dst, pend, lane, words, bits);
+    merge_and_flush<stage_ne(LC), ABL, true, DPP>(buf, cap, tot, sp, dst, pend, lane, words, bits);
 }
 
 // Last, partial chunk of a channel (m < 16384 samples).  Its full pieces (16 samples) take the same
@@ -675,7 +678,7 @@ __device__ __noinline__ uint4 encode_partial_chunk(const MH_AS_GLOBAL uint8_t *s
     if (LC >= 2 && __any(sp > cap))
         overflow_chunk<true, PK>(src, m, lut1, buf, dst, pend, lane, words, bits);
     else
-        merge_and_flush<NE, 0, false>(buf, cap, tot, sp, dst, pend, lane, words, bits);
+        merge_and_flush<NE, 0, false, true>(buf, cap, tot, sp, dst, pend, lane, words, bits);
     return make_uint4(words, bits, pend, (uint32_t)(dst - dst0));
 }
 
@@ -699,6 +702,7 @@ __device__ __forceinline__ void load_first_rows(typename RawPiece<PK>::type (&v)
 // otherwise the caller does (the shared-table kernel publishes a whole task at once: one 32-byte store and one
 // atomic per workgroup instead of four scattered 8-byte stores and four atomics -- 313 000 of each per launch on
 // the 1024 x 1e7 set cost 0.06 ms, tools/ablate_encode.py level 15).
+// PUBLISH (the wave-task kernels: a wave is a task of its own) also selects the DPP reductions in the chunks' merge.
 template <int LC, int PB, int ABL, bool PRE, int PK, bool PUBLISH = true>
 __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, uint32_t ch, const uint8_t *src, uint64_t n,
                                                uint32_t *__restrict__ out, typename RawPiece<PK>::type (&v)[kWin], const uint2 *lut2,
@@ -715,12 +719,12 @@ __device__ __forceinline__ void encode_segment(const EncArgs &e, uint32_t seg, u
         if (!PRE) load_first_rows<PK>(v, src, lane);
         uint32_t w, b;
         for (uint32_t c = 0; c + 1 < nfull; ++c) {
-            encode_full_chunk<LC, PB, ABL, true, PK>(v, src + (size_t)c * cstride, src + (size_t)(c + 1) * cstride, lut2, lut1, buf,
+            encode_full_chunk<LC, PB, ABL, true, PK, PUBLISH>(v, src + (size_t)c * cstride, src + (size_t)(c + 1) * cstride, lut2, lut1, buf,
                                                      cap, out, pend, lane, w, b);
             words += w;
             bits += b;
         }
-        encode_full_chunk<LC, PB, ABL, false, PK>(v, src + (size_t)(nfull - 1) * cstride, src, lut2, lut1, buf, cap, out, pend,
+        encode_full_chunk<LC, PB, ABL, false, PK, PUBLISH>(v, src + (size_t)(nfull - 1) * cstride, src, lut2, lut1, buf, cap, out, pend,
                                                   lane, w, b);
         words += w;
         bits += b;
@@ -1674,6 +1678,12 @@ __global__ __launch_bounds__(256) void k_hist2(HistArgs a, uint32_t S)
     __shared__ __attribute__((aligned(16))) unsigned long long tab[256];
     __shared__ uint32_t red[MH_LUT_SYMS][4];
     const int tid = threadIdx.x;
+    // (the tile's directory entries are requested before the table is built: two dependent round trips that the
+    // build and its barrier overlap)
+    const uint32_t tile = blockIdx.x;
+    const uint32_t ch = a.tile_ch[tile];
+    const uint8_t *p = a.data + a.ch_off[ch] + a.tile_start[tile];
+    const uint32_t n = a.tile_n[tile];
     {
         const uint32_t m = (1u << PB) - 1u;
         if ((uint32_t)tid < (1u << (2 * PB))) {
@@ -1686,10 +1696,6 @@ __global__ __launch_bounds__(256) void k_hist2(HistArgs a, uint32_t S)
         }
     }
     __syncthreads();
-    const uint32_t tile = blockIdx.x;
-    const uint32_t ch = a.tile_ch[tile];
-    const uint8_t *p = a.data + a.ch_off[ch] + a.tile_start[tile];
-    const uint32_t n = a.tile_n[tile];
     uint32_t cnt[MH_LUT_SYMS];
 #pragma unroll
     for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] = 0;
@@ -1711,26 +1717,42 @@ __global__ __launch_bounds__(256) void k_hist2(HistArgs a, uint32_t S)
     constexpr uint32_t kHiMask = 0x01010101u * (0xFFu & ~((1u << PB) - 1u));
     const u32x4 *q = reinterpret_cast<const u32x4 *>(p + head);
     int pending = 0;
-    for (uint32_t i = tid; i < nvec; i += 256) {
-        u32x4 x = __builtin_nontemporal_load(q + i);
-        const uint32_t hi = (x.x | x.y | x.z | x.w) & kHiMask;
-        if (__any(hi != 0)) {
-            x.x = clip_word<PB>(x.x);
-            x.y = clip_word<PB>(x.y);
-            x.z = clip_word<PB>(x.z);
-            x.w = clip_word<PB>(x.w);
+    // Four vectors are requested before the first is looked at: the wave-wide test for bytes that need clipping makes
+    // every iteration wait for its load, and one vector per trip left a short tile (a 72 000-bin channel: 9 vectors
+    // per thread) paying the memory latency nine times over -- measure, S = 4..10: 2400 x 72 000 bins 32.7-35.3 ->
+    // 29.7-32.4 us, 1024 x 1e7 bins 1.69-1.77 -> 1.60-1.62 ms (profiles/r03_dpp_reductions.txt).
+    constexpr int kAhead = 4;
+    for (uint32_t i = tid; i < nvec; i += 256 * kAhead) {
+        u32x4 xs[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const uint32_t j = i + 256u * (uint32_t)u;
+            xs[u] = __builtin_nontemporal_load(q + (j < nvec ? j : i));  // (past the end: vector i again, not used)
         }
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const uint32_t y = pair_index_word<PB>(x[d]);
-            acc += tab[y & 0xFFu];
-            acc += tab[(y >> 16) & 0xFFu];
-        }
-        if (++pending == 3) {  // <= 1 (head/tail) + 3 * 16 = 49 per field
-            pending = 0;
+        for (int u = 0; u < kAhead; ++u) {
+            if (i + 256u * (uint32_t)u < nvec) {
+                u32x4 x = xs[u];
+                const uint32_t hi = (x.x | x.y | x.z | x.w) & kHiMask;
+                if (__any(hi != 0)) {
+                    x.x = clip_word<PB>(x.x);
+                    x.y = clip_word<PB>(x.y);
+                    x.z = clip_word<PB>(x.z);
+                    x.w = clip_word<PB>(x.w);
+                }
 #pragma unroll
-            for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] += (uint32_t)(acc >> (6 * s)) & 63u;
-            acc = 0;
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t y = pair_index_word<PB>(x[d]);
+                    acc += tab[y & 0xFFu];
+                    acc += tab[(y >> 16) & 0xFFu];
+                }
+                if (++pending == 3) {  // <= 1 (head/tail) + 3 * 16 = 49 per field
+                    pending = 0;
+#pragma unroll
+                    for (int s = 0; s < MH_LUT_SYMS; ++s) cnt[s] += (uint32_t)(acc >> (6 * s)) & 63u;
+                    acc = 0;
+                }
+            }
         }
     }
 #pragma unroll

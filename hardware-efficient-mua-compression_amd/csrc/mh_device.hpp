@@ -48,11 +48,19 @@ __host__ __device__ inline int symbol_of_rank(int mode, int S, int p, int k)
     return a > b ? p - j : p + j;
 }
 
+// Sum over the 64 lanes, the same value in every lane.  Six DPP adds (within a row of 16 lanes: row_shr 1, 2, 4, 8
+// under bank masks; across rows: row_bcast 15 and 31) leave the total in lane 63 and v_readlane broadcasts it: no LDS
+// crossbar round trips (six dependent ds_bpermute per sum before; the histogram kernels and the calibration reduce
+// ten counters each).  All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, true);   // row_shr:4, lanes 4..15 of a row
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, true);   // row_shr:8, lanes 8..15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // inclusive prefix sum over the 64 lanes of a wave
@@ -66,11 +74,57 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane)
     return v;
 }
 
-// ---- chunk header, format revision 2 ---------------------------------------------------------
-//   bits [0,12)  min  = shortest sub-stream length of the chunk (<= 256 * 9)
-//   bits [12,16) w    = bits needed for (longest - shortest), 0..12
-//   then 64 fields of w bits (sub-stream length - min), LSB-first from bit 16;
-//   header words = ceil((16 + 64 w) / 32) = 1..25 (kHdrWords = 32 stays the bound slots are sized by)
+// The same scan in six DPP adds (a Hillis-Steele scan inside each row of 16 lanes, then row_bcast 15 / 31 carry the row
+// totals upwards; lanes without a source add the identity 0).  All 64 lanes must be active.
+// WHICH ONE: the DPP forms keep a reduction off the LDS crossbar -- a sixth of the latency, which is what a short
+// launch waits for (wave-task encoders, partial chunks, histogram and calibration tails) -- but they are VALU work,
+// and the long-channel S <= 5 encoders have none to spare: 1024 ch x 1e7 bins, S = 3 encode 1.995 -> 2.045 ms with
+// DPP scan / min / max in the merge, where the ds_bpermute forms wait on an otherwise idle pipe
+// (profiles/r03_dpp_reductions.txt).
+__device__ __forceinline__ uint32_t wave_scan_incl_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// the value lane 63 holds (e.g. the total behind wave_scan_incl), in every lane: one v_readlane, no LDS crossbar
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+
+// min / max over the 64 lanes in every lane: the DPP ladder of wave_sum_u32 with the operation's identity for lanes
+// without a source
+#define MH_DPP_STEP(v, ident, ctrl, rmask, op)                                                                     \
+    {                                                                                                              \
+        const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(ident), (int)(v), ctrl, rmask, 0xf, false); \
+        v = op(t_, v);                                                                                             \
+    }
+#define MH_DPP_REDUCE(v, ident, op)        \
+    MH_DPP_STEP(v, ident, 0x111, 0xf, op)  \
+    MH_DPP_STEP(v, ident, 0x112, 0xf, op)  \
+    MH_DPP_STEP(v, ident, 0x114, 0xf, op)  \
+    MH_DPP_STEP(v, ident, 0x118, 0xf, op)  \
+    MH_DPP_STEP(v, ident, 0x142, 0xa, op)  \
+    MH_DPP_STEP(v, ident, 0x143, 0xc, op)
+
+__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v)
+{
+    MH_DPP_REDUCE(v, 0xFFFFFFFFu, min_u32)
+    return wave_last(v);
+}
+
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
+{
+    MH_DPP_REDUCE(v, 0u, max_u32)
+    return wave_last(v);
+}
+
 __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 {
 #pragma unroll
@@ -102,6 +156,11 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// ---- chunk header, format revision 2 ---------------------------------------------------------
+//   bits [0,12)  min  = shortest sub-stream length of the chunk (<= 256 * 9)
+//   bits [12,16) w    = bits needed for (longest - shortest), 0..12
+//   then 64 fields of w bits (sub-stream length - min), LSB-first from bit 16;
+//   header words = ceil((16 + 64 w) / 32) = 1..25 (kHdrWords = 32 stays the bound slots are sized by)
 __host__ __device__ __forceinline__ uint32_t hdr_words(uint32_t w) { return (16u + 64u * w + 31u) >> 5; }
 
 // field width for sub-stream lengths spanning `range` = longest - shortest

@@ -178,6 +178,7 @@ struct FinArgs {
     const uint64_t *w0, *w1;
     const uint8_t *skipflag;
     const uint8_t *peak, *enc, *sclv;
+    const uint32_t *sclv16;  // the SCLV rows padded to 16 bytes (CalArgs::sclv16)
     uint32_t C, S, mode;
     uint64_t *post;   // C*S rank order, may be NULL
     uint64_t *bits;   // may be NULL
@@ -190,8 +191,13 @@ template <bool COHERENT>
 __device__ __forceinline__ void finalize_channel(const FinArgs &a, uint32_t ch, int p, uint32_t enc)
 {
     const int S = (int)a.S;
+    // Everything this needs is loaded BEFORE the first store: the byte-typed outputs may alias anything, so a load behind a
+    // store is issued only once the store is -- one serialised L2 round trip per code length (S = 10: 7 us per channel
+    // in the one-launch measure, where this runs on one lane at the end of a workgroup).
     const uint64_t n = a.w1[ch] - a.w0[ch];
-    const uint8_t *row = a.sclv + (size_t)enc * S;
+    const u32x4 row4 = *reinterpret_cast<const u32x4 *>(a.sclv16 + (size_t)enc * 4);
+    const uint64_t row_lo = (uint64_t)row4.x | ((uint64_t)row4.y << 32), row_hi = (uint64_t)row4.z | ((uint64_t)row4.w << 32);
+    const uint8_t skipf = a.skipped ? a.skipflag[ch] : (uint8_t)0;
     uint64_t h[MH_LUT_SYMS];
     uint64_t rest = 0, b = 0;
 #pragma unroll
@@ -210,10 +216,10 @@ __device__ __forceinline__ void finalize_channel(const FinArgs &a, uint32_t ch, 
         for (int s = 0; s < MH_LUT_SYMS; ++s)
             if (s == sym && s < S - 1) v = h[s];
         if (a.post) a.post[(size_t)ch * S + k] = v;  // get_BR_with_approx_sort.py:193
-        b += (uint64_t)row[k] * v;                    // :289 numerator
+        b += (((k < 8 ? row_lo : row_hi) >> (8 * (k & 7))) & 0xFFu) * v;  // :289 numerator
     }
     if (a.bits) a.bits[ch] = b;
-    if (a.skipped) a.skipped[ch] = a.skipflag[ch];
+    if (a.skipped) a.skipped[ch] = skipf;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -649,6 +649,7 @@ int mh_measure(mh_plan *p, const uint8_t *data, uint64_t *cutoff, uint32_t *cal_
     f.peak = pk;
     f.enc = en;
     f.sclv = p->d_sclv;
+    f.sclv16 = p->d_sclv16;
     f.C = p->h.info.C;
     f.S = p->h.info.S;
     f.mode = p->h.info.mode;

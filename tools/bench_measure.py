@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import muahuff
+if os.environ.get("LIB"):  # another build of the library (same-box A/B)
+    muahuff._lib.use_library(os.path.abspath(os.environ["LIB"]))
 from muahuff import codec, sclv, synth
 
 C, T = int(os.environ.get("C", "1024")), 10_000_000

@@ -2,6 +2,8 @@ import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 import muahuff
+if os.environ.get("LIB"):  # another build of the library (same-box A/B)
+    muahuff._lib.use_library(os.path.abspath(os.environ["LIB"]))
 from muahuff import codec, sclv, synth
 def timed(f, n=40):
     for _ in range(5): f()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Short channels: what a launch costs before any streaming -- encode / decode / measure of C channels x T bins for T
-from 'calibration window only' to a few chunks (event-timed, median).  usage: small_decompose.py [C] [S]"""
+from 'calibration window only' to a few chunks (event-timed, median).  usage: [LIB=other.so] small_decompose.py [C] [S]"""
 import os
 import sys
 
@@ -9,6 +9,8 @@ import numpy as np
 import torch
 
 import muahuff
+if os.environ.get("LIB"):  # another build of the library (same-box A/B)
+    muahuff._lib.use_library(os.path.abspath(os.environ["LIB"]))
 from muahuff import codec, sclv, synth
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 2400
