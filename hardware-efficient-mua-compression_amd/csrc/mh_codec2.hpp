@@ -1556,7 +1556,7 @@ __device__ __forceinline__ uint32_t build_decode_tables(const Dec2Args &a, uint3
     const uint32_t mine = lane < S ? code | ((uint32_t)symbol_of_rank((int)a.mode, S, p, lane) << 24) : 0u;
     uint32_t rk[MH_LUT_SYMS];
 #pragma unroll
-    for (int r = 0; r < MH_LUT_SYMS; ++r) rk[r] = __shfl(mine, r, 64);
+    for (int r = 0; r < MH_LUT_SYMS; ++r) rk[r] = (uint32_t)__builtin_amdgcn_readlane((int)mine, r);  // (scalar: no LDS crossbar)
     uint32_t L = 0;  // rows are non-decreasing: the last rank has the longest code
 #pragma unroll
     for (int r = 0; r < MH_LUT_SYMS; ++r)

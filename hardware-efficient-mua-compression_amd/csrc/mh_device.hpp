@@ -135,15 +135,23 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v)
     return v;
 }
 
+// (64-bit minimum in every lane: the same DPP ladder on both halves; used once per channel by the calibration)
+#define MH_DPP_STEP64_MIN(v, ctrl, rmask)                                                                                    \
+    {                                                                                                                        \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v), ctrl, rmask, 0xf, false);         \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)((v) >> 32), ctrl, rmask, 0xf, false); \
+        const uint64_t t_ = (uint64_t)lo_ | ((uint64_t)hi_ << 32);                                                           \
+        v = t_ < v ? t_ : v;                                                                                                 \
+    }
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)v, d, 64), hi = __shfl_xor((uint32_t)(v >> 32), d, 64);
-        const uint64_t t = (uint64_t)lo | ((uint64_t)hi << 32);
-        v = t < v ? t : v;
-    }
-    return v;
+    MH_DPP_STEP64_MIN(v, 0x111, 0xf)
+    MH_DPP_STEP64_MIN(v, 0x112, 0xf)
+    MH_DPP_STEP64_MIN(v, 0x114, 0xf)
+    MH_DPP_STEP64_MIN(v, 0x118, 0xf)
+    MH_DPP_STEP64_MIN(v, 0x142, 0xa)
+    MH_DPP_STEP64_MIN(v, 0x143, 0xc)
+    return (uint64_t)wave_last((uint32_t)v) | ((uint64_t)wave_last((uint32_t)(v >> 32)) << 32);
 }
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t v)

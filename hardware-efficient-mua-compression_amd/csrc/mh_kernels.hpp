@@ -496,7 +496,7 @@ __device__ __forceinline__ void wave_calibrate_finish(const CalLoads &l, const u
         const uint32_t kk = (cost << 8) | k;
         key = kk < key ? kk : key;
     }
-    key = wave_min(key);
+    key = wave_min_dpp(key);
     p_out = p;
     k_out = key & 0xFFu;
 }
