@@ -1573,22 +1573,17 @@ __device__ __forceinline__ uint32_t build_decode_tables(const Dec2Args &a, uint3
         tab1[j] = (uint8_t)e;
     }
     if (K == 4) {  // the next W = 8 bits always hold 4 whole codewords -> {symbols spread to bytes, bits}
+        // four lookups in the per-symbol table just built (as the pair table below) instead of matching every rank
+        // against every one of the four positions: a wave that builds its own table (wave-task plans) spent 1.6 us
+        // of a 7-us one-chunk record here
+        table_sync<NT>();
         for (uint32_t idx = (uint32_t)t; idx < (1u << W); idx += NT) {
             uint32_t bpos = 0, bytes = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                uint32_t hit_sym = 0, hit_len = 0;
-#pragma unroll
-                for (int r = 0; r < MH_LUT_SYMS; ++r)
-                    if (r < S) {
-                        const uint32_t l = (rk[r] >> 16) & 0xFFu;
-                        if (((idx >> bpos) & ((1u << l) - 1u)) == (rk[r] & 0xFFFFu)) {
-                            hit_sym = rk[r] >> 24;
-                            hit_len = l;
-                        }
-                    }
-                bytes |= hit_sym << (8 * j);
-                bpos += hit_len;
+                const uint32_t e = tab1[(idx >> bpos) & mask1];
+                bytes |= (e & 15u) << (8 * j);
+                bpos += e >> 4;
             }
             reinterpret_cast<uint2 *>(tab)[idx] = make_uint2(bytes, bpos);
         }
