@@ -995,16 +995,19 @@ struct ChunkHdr {
 };
 
 // hw32: word (lane & 31) of the chunk (a full chunk is longer than 32 words)
+// DPP: the prefix sum of the 64 sub-stream lengths as a DPP ladder (mh_device.hpp) -- the decoders whose VALU has room
+// (all but the plain pair-table ones, S = 4..6) take it: S = 3 decode -0.7 %, S = 8 -1.4 % on 1024 ch x 1e7 bins.
+template <bool DPP = false>
 __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw32, int lane)
 {
     uint32_t wid;
     const uint32_t len = hdr_len_from_wave(hw32, lane, wid);
-    const uint32_t incl = wave_scan_incl(len, lane);
+    const uint32_t incl = DPP ? wave_scan_incl_dpp(len) : wave_scan_incl(len, lane);
     ChunkHdr h;
     h.P = incl - len;
     // chunk sizes are wave-uniform: keep them in scalar registers (the stream pointers and the
     // bounds checks derived from them then cost no vector registers)
-    h.nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)((__shfl(incl, 63, 64) + 31) >> 5));
+    h.nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((DPP ? wave_last(incl) : __shfl(incl, 63, 64)) + 31) >> 5));
     h.hw = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr_words(wid));
     return h;
 }
@@ -1316,6 +1319,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
                                                const uint32_t *tab, uint32_t tbase, uint32_t maskW, const uint8_t *tab1,
                                                uint32_t mask1, uint32_t *stage, int lane)
 {
+    constexpr bool kHdrDpp = !(K == 2 && !HY);  // see scan_header
     constexpr uint32_t kCap = NR * 64;         // words of payload (+3 read-ahead) a staged chunk may have
     constexpr int NV = (NR + 3) / 4;           // 16-byte vectors per lane that cover kCap words
     // Untrusted input: `pos` = word index of a chunk's first header word, `lim` = words that may be
@@ -1345,7 +1349,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
     uint32_t c = 0;  // next chunk the per-symbol loop below would have to decode
     if (nfull) {
         if (!room(pos, 32)) MH_DEC_BAIL();
-        ChunkHdr hc = scan_header(in[lane & 31], lane);  // chunk whose payload is (about to be) in LDS
+        ChunkHdr hc = scan_header<kHdrDpp>(in[lane & 31], lane);  // chunk whose payload is (about to be) in LDS
         if (hc.nw < kMinFull || !room(pos, (uint64_t)hc.hw + hc.nw + 3 + (nfull > 1 ? 32 : 0))) MH_DEC_BAIL();
         u32x4 R[NV];
         // NV x 1 KiB; lanes past the chunk's own av = nw + 3 words all re-read its last vector (one
@@ -1385,7 +1389,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
             asm volatile("" ::"v"(hw_next));
             if (nfull > 1) {
                 pos_n += hc.hw + hc.nw;
-                nx = scan_header(hw_next, lane);
+                nx = scan_header<kHdrDpp>(hw_next, lane);
                 if (nx.nw < kMinFull || !room(pos_n, (uint64_t)nx.hw + nx.nw + 3 + (nfull > 2 ? 32 : 0))) MH_DEC_BAIL();
                 pay_n += hc.nw + nx.hw;
                 avail_n = nx.nw + 3;
@@ -1419,7 +1423,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
                 if (c + 1 < nfull) {  // scalar bookkeeping: header(c+1) from hw_next
                     pos_n += nx.hw + nx.nw;
                     pay_n += nx.nw;
-                    nx = scan_header(hw_next, lane);
+                    nx = scan_header<kHdrDpp>(hw_next, lane);
                     if (nx.nw < kMinFull || !room(pos_n, (uint64_t)nx.hw + nx.nw + 3 + (c + 2 < nfull ? 32 : 0))) MH_DEC_BAIL();
                     pay_n += nx.hw;
                     avail_n = nx.nw + 3;
@@ -1433,7 +1437,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
     }
     for (; c < nfull; ++c) {  // (rest of) a segment that holds an oversize chunk: per-symbol routine
         if (!room(pos, 32)) MH_DEC_BAIL();
-        const ChunkHdr h = scan_header(in[lane & 31], lane);
+        const ChunkHdr h = scan_header<kHdrDpp>(in[lane & 31], lane);
         if (h.nw < kMinFull || !room(pos, (uint64_t)h.hw + h.nw + 3)) MH_DEC_BAIL();
         decode_chunk<3, true>(in, kChunk, tab1, mask1, out + (size_t)c * kChunk, lane);
         in += h.hw + h.nw;
@@ -1456,6 +1460,7 @@ __device__ __forceinline__ void decode_segment_dual(const DecArgs &d, uint64_t p
                                                     uint32_t mask1, uint32_t *stage, int lane)
 {
     static_assert(K == 1 && !HY, "pairing is for the branch-free one-symbol loop");
+    constexpr bool kHdrDpp = true;
     constexpr uint32_t kCap = NR * 64;
     constexpr int NV = (NR + 3) / 4;
     constexpr uint32_t kMinFull = kChunk / 32;
@@ -1469,14 +1474,14 @@ __device__ __forceinline__ void decode_segment_dual(const DecArgs &d, uint64_t p
             return;
         }
         const uint32_t *in = d.payload + pos;
-        const ChunkHdr hA = scan_header(in[lane & 31], lane);
+        const ChunkHdr hA = scan_header<kHdrDpp>(in[lane & 31], lane);
         // header A, payload A and the first 32 words of chunk B (a full chunk is longer than that) must be there
         if (hA.nw < kMinFull || !room(pos, (uint64_t)hA.hw + hA.nw + 32)) {
             if (lane == 0) atomicMax(d.err, d.epoch);
             return;
         }
         const uint32_t *payA = in + hA.hw;
-        const ChunkHdr hB = scan_header(payA[hA.nw + (uint32_t)(lane & 31)], lane);
+        const ChunkHdr hB = scan_header<kHdrDpp>(payA[hA.nw + (uint32_t)(lane & 31)], lane);
         const uint64_t posB = pos + hA.hw + hA.nw;
         if (hB.nw < kMinFull || !room(posB, (uint64_t)hB.hw + hB.nw + 3)) {
             if (lane == 0) atomicMax(d.err, d.epoch);
