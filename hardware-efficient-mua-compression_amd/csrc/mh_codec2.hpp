@@ -274,6 +274,9 @@ template <int PK>
 __device__ __forceinline__ typename RawPiece<PK>::type load_row(const uint8_t *p)
 {
     if constexpr (PK == 0) {
+#ifdef MH_ROW_PLAIN  // A/B builds: plain instead of non-temporal row loads
+        return *reinterpret_cast<const u32x4_u *>(p);
+#endif
         return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
     } else if constexpr (PK == 4) {
         typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
@@ -564,9 +567,29 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     uint64_t acc = 0;
     uint32_t nb = 0, sp = 0;
     uint32_t *st = stage_lane_base(buf, cap, lane);
+#ifndef MH_ROW_GLOBAL  // (A/B builds: -DMH_ROW_GLOBAL = global loads for the rows, as before)
+    // Byte input: the rows of a chunk through a buffer resource on the chunk's first byte (wave-uniform: four scalar
+    // registers) -- the row is an immediate / scalar offset and the lane's 16 bytes one vector register, where a
+    // global load needs a 64-bit vector address per row (two VALU adds); and the cache policy is an operand of the
+    // instruction (aux = 2: nt), not metadata an IR pass may drop (it did, for seven of a chunk's sixteen rows).
+    // 1024 ch x 1e7 bins encode S = 5 / 8 -1.5 %, S = 3 -1 %; 2400 x 72 000 S = 10 -3 % (profiles/r03_dpp_reductions.txt).
+    // (96 ch x 3.6e6 bins in a loop over the SAME 345 MB reads 7 % slower: fewer of its rows now stay in the Infinity
+    // Cache between iterations -- a property of re-reading one small input, not of a recording that is read once.)
+    const auto rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(cur), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rs_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(nxt), 0, 0x7FFFFFFF, 0x00020000);
+    const int voff = lane * 16;
+#endif
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         const typename RawPiece<PK>::type raw = v[k & (kWin - 1)];
+#ifndef MH_ROW_GLOBAL
+        if constexpr (PK == 0) {
+            if (k < kRows - kWin)
+                v[k & (kWin - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, voff, (k + kWin) * 1024, 2);
+            else if (HAS_NEXT)
+                v[k & (kWin - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rs_nxt, voff, (k + kWin - kRows) * 1024, 2);
+        } else
+#endif
         if (k < kRows - kWin)
             v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
         else if (HAS_NEXT)
