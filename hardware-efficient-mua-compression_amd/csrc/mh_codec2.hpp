@@ -1045,7 +1045,15 @@ __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw32, int lane)
 // PARTIAL: the chunk holds m < 16384 samples.  Rows past the last sample are skipped (wave-uniform),
 // lanes whose piece is not complete skip the row, and the one cut piece (m % 16 samples) is decoded
 // symbol by symbol from the same window.
-template <int K, int M, int RL, bool HY, bool PARTIAL = false>
+// ST: how a decoded row leaves.  0 = global store (the long-channel kernels and the one-symbol decoder); 1 / 2 =
+// through a buffer resource on the chunk's first output byte with the default / the nt cache policy (no 64-bit vector
+// address per row).  The wave-task decoders of S <= 6 use 1: 2400 x 72 000 decode S = 3 41 -> 35.5 us, S = 5 47.7 -> 45 us;
+// 10 000 x 20 000 S = 3 55 -> 40.6 us, S = 5 60 -> 53.5 us.  The long-channel kernels LOSE with either buffer form (S = 3:
+// 1.95 -> 2.25 ms with the default policy, 2.0-2.1 with nt): a decoder that gets its rows out faster writes worse on
+// this part (cf. the occupancy cap); the one-symbol decoder loses 4 % (profiles/r03_dpp_reductions.txt).
+// (The source asks for non-temporal global stores; all but one of a kernel's 33 lose that metadata in an IR pass --
+// seen in the ISA -- so "global store" means the default policy.)
+template <int K, int M, int RL, bool HY, bool PARTIAL = false, int ST = 0>
 __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *tabw, uint32_t tbase, uint32_t maskW,
                                                     const uint8_t *tab1, uint32_t mask1,
                                                     const uint32_t *stage, uint8_t *__restrict__ out,
@@ -1085,6 +1093,7 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
 #ifdef MH_TUNING
     const int dec_abl = __builtin_amdgcn_readfirstlane(d_dec_abl);  // once per chunk: the row stores below may alias it
 #endif
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7FFFFFFF, 0x00020000);  // (ST != 0)
     auto row = [&](int k) {
         const uint32_t piece = (uint32_t)k * kLanes + lane;
         if (PARTIAL && piece >= nfp) {
@@ -1186,6 +1195,14 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
             return;
         }
 #endif
+        if (!PARTIAL && ST != 0) {
+            // (the row offset is part of the VECTOR offset -- the compiler folds what fits into the immediate: with a scalar-
+            // register offset hipcc 7.2 leaves no wait state between this store and a VALU write of its data
+            // registers -- GCNHazardRecognizer assumes that form has no such hazard -- and gfx950 then stores the
+            // new value in lanes 12..15 of every 16: seen as wrong symbols in row 14 of a chunk)
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, lane * MH_PIECE + (int)krow * kLanes * MH_PIECE, 0, ST == 2 ? 2 : 0);
+            return;
+        }
         __builtin_nontemporal_store(o, reinterpret_cast<u32x4_u *>(out + (krow * kLanes + lane) * MH_PIECE));
     };
     if (PARTIAL) {  // a rolled loop keeps the rarely run instance small (registers and code)
@@ -1205,7 +1222,7 @@ __device__ __forceinline__ void decode_staged_chunk(ChunkHdr h, const uint32_t *
 // independent chains -- the same lane's sub-streams in two chunks -- interleave perfectly: their lookups are issued back
 // to back and each LDS round trip serves both.  (The same pairing around the hybrid loop was slower: its branches cut
 // the two chains into separate basic blocks, r03_pair_decoding_ab.txt.)
-template <int M, int RL>
+template <int M, int RL, int ST = 0>
 __device__ __forceinline__ void decode_staged_pair1(ChunkHdr hA, ChunkHdr hB, const uint8_t *tab1, uint32_t mask1,
                                                     const uint32_t *stageA, const uint32_t *stageB,
                                                     uint8_t *__restrict__ outA, uint8_t *__restrict__ outB, int lane)
@@ -1226,6 +1243,8 @@ __device__ __forceinline__ void decode_staged_pair1(ChunkHdr hA, ChunkHdr hB, co
     };
     start(A, stageA, hA.P);
     start(B, stageB, hB.P);
+    const auto rs_A = __builtin_amdgcn_make_buffer_rsrc(outA, 0, 0x7FFFFFFF, 0x00020000);  // (ST != 0: see decode_staged_chunk)
+    const auto rs_B = __builtin_amdgcn_make_buffer_rsrc(outB, 0, 0x7FFFFFFF, 0x00020000);
     auto top_up = [&](Chain &c) {
         if (RL == 2) {
             const bool t = c.bp >= 32;
@@ -1264,8 +1283,13 @@ __device__ __forceinline__ void decode_staged_pair1(ChunkHdr hA, ChunkHdr hB, co
             oA[d] = wA;
             oB[d] = wB;
         }
-        __builtin_nontemporal_store(oA, reinterpret_cast<u32x4_u *>(outA + ((uint32_t)k * kLanes + lane) * MH_PIECE));
-        __builtin_nontemporal_store(oB, reinterpret_cast<u32x4_u *>(outB + ((uint32_t)k * kLanes + lane) * MH_PIECE));
+        if (ST != 0) {
+            __builtin_amdgcn_raw_buffer_store_b128(oA, rs_A, lane * MH_PIECE + k * kLanes * MH_PIECE, 0, ST == 2 ? 2 : 0);
+            __builtin_amdgcn_raw_buffer_store_b128(oB, rs_B, lane * MH_PIECE + k * kLanes * MH_PIECE, 0, ST == 2 ? 2 : 0);
+        } else {
+            __builtin_nontemporal_store(oA, reinterpret_cast<u32x4_u *>(outA + ((uint32_t)k * kLanes + lane) * MH_PIECE));
+            __builtin_nontemporal_store(oB, reinterpret_cast<u32x4_u *>(outB + ((uint32_t)k * kLanes + lane) * MH_PIECE));
+        }
     }
 }
 
@@ -1337,12 +1361,13 @@ __device__ __forceinline__ void decode_partial_chunk(const uint32_t *__restrict_
 // The oversize-chunk slow path has loads of its own and therefore sits OUTSIDE the loop: the
 // first chunk that does not fit the staging area ends it and the rest of the segment goes chunk
 // by chunk through decode_chunk (adversarial data only).
-template <int K, int M, int NR, int RL, bool HY>
+template <int K, int M, int NR, int RL, bool HY, bool WT = false>
 __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, uint8_t *__restrict__ out, uint64_t n,
                                                const uint32_t *tab, uint32_t tbase, uint32_t maskW, const uint8_t *tab1,
                                                uint32_t mask1, uint32_t *stage, int lane)
 {
     constexpr bool kHdrDpp = !(K == 2 && !HY);  // see scan_header
+    constexpr int kSt = WT && K != 1 ? 1 : 0;  // see decode_staged_chunk
     constexpr uint32_t kCap = NR * 64;         // words of payload (+3 read-ahead) a staged chunk may have
     constexpr int NV = (NR + 3) / 4;           // 16-byte vectors per lane that cover kCap words
     // Untrusted input: `pos` = word index of a chunk's first header word, `lim` = words that may be
@@ -1426,7 +1451,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
                 // flight before this chunk's stores
                 fetch(pay_n, avail_n);
                 hw_next = peek(pay_n, nx.nw, peek_n);
-                decode_staged_chunk<K, M, RL, HY>(hc, tab, tbase, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
+                decode_staged_chunk<K, M, RL, HY, false, kSt>(hc, tab, tbase, maskW, tab1, mask1, stage, out + (size_t)c * kChunk, lane);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 ++c;
@@ -1477,7 +1502,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
 // payload B -- contiguous in the stream -- into the wave's staging area, and the two chunks decode side by side.
 // Whatever does not fit that scheme goes through decode_segment: a pair too large for the staging area, the odd full
 // chunk, the partial chunk.  Same bounds rules: every header-steered read is checked against lim first.
-template <int K, int M, int NR, int RL, bool HY>
+template <int K, int M, int NR, int RL, bool HY, bool WT = false>
 __device__ __forceinline__ void decode_segment_dual(const DecArgs &d, uint64_t pos, uint8_t *__restrict__ out, uint64_t n,
                                                     const uint32_t *tab, uint32_t tbase, uint32_t maskW, const uint8_t *tab1,
                                                     uint32_t mask1, uint32_t *stage, int lane)
@@ -1527,7 +1552,7 @@ __device__ __forceinline__ void decode_segment_dual(const DecArgs &d, uint64_t p
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        decode_staged_pair1<M, RL>(hA, hB, tab1, mask1, stage, stage + hA.nw + hB.hw, out + (size_t)c * kChunk,
+        decode_staged_pair1<M, RL, 0>(hA, hB, tab1, mask1, stage, stage + hA.nw + hB.hw, out + (size_t)c * kChunk,
                                    out + (size_t)(c + 1) * kChunk, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1535,7 +1560,7 @@ __device__ __forceinline__ void decode_segment_dual(const DecArgs &d, uint64_t p
         c += 2;
     }
     if ((uint64_t)c * kChunk < n)
-        decode_segment<K, M, NR, RL, HY>(d, pos, out + (size_t)c * kChunk, n - (uint64_t)c * kChunk, tab, tbase, maskW, tab1, mask1,
+        decode_segment<K, M, NR, RL, HY, WT>(d, pos, out + (size_t)c * kChunk, n - (uint64_t)c * kChunk, tab, tbase, maskW, tab1, mask1,
                                          stage, lane);
 }
 
@@ -1681,10 +1706,10 @@ __global__ __launch_bounds__(256, MH_DEC_MIN_WAVES) void k_decode2w(Dec2Args a)
     const uint32_t mask1 = build_decode_tables<K, 64>(a, t.ch, tab, tab1, lane, lane);
     const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tab;
     if constexpr (DUAL)
-        decode_segment_dual<K, M, NR, RL, HY>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
+        decode_segment_dual<K, M, NR, RL, HY, true>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
                                               tab + dec2_shared_dwords(W, K), lane);
     else
-        decode_segment<K, M, NR, RL, HY>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
+        decode_segment<K, M, NR, RL, HY, true>(a.d, pos, a.d.out + t.src_off, t.n, tab, tbase, (1u << W) - 1u, tab1, mask1,
                                          tab + dec2_shared_dwords(W, K), lane);
 }
 
