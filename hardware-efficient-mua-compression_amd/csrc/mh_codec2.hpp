@@ -568,7 +568,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     uint32_t nb = 0, sp = 0;
     uint32_t *st = stage_lane_base(buf, cap, lane);
 #ifndef MH_ROW_GLOBAL  // (A/B builds: -DMH_ROW_GLOBAL = global loads for the rows, as before)
-    // Byte input: the rows of a chunk through a buffer resource on the chunk's first byte (wave-uniform: four scalar
+    // The rows of a chunk through a buffer resource on the chunk's first byte (wave-uniform: four scalar
     // registers) -- the row is an immediate / scalar offset and the lane's 16 bytes one vector register, where a
     // global load needs a 64-bit vector address per row (two VALU adds); and the cache policy is an operand of the
     // instruction (aux = 2: nt), not metadata an IR pass may drop (it did, for seven of a chunk's sixteen rows).
@@ -577,23 +577,32 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     // Cache between iterations -- a property of re-reading one small input, not of a recording that is read once.)
     const auto rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(cur), 0, 0x7FFFFFFF, 0x00020000);
     const auto rs_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(nxt), 0, 0x7FFFFFFF, 0x00020000);
-    const int voff = lane * 16;
+    const int voff = lane * (int)piece_bytes<PK>();
+    constexpr int kRowBytes = kLanes * (int)piece_bytes<PK>();
+    auto row_load = [&](const auto &rs, int row) {  // (packed pieces: 8 / 4 bytes per lane, the same form)
+        if constexpr (PK == 0) {
+            return (typename RawPiece<PK>::type)__builtin_amdgcn_raw_buffer_load_b128(rs, voff, row * kRowBytes, 2);
+        } else if constexpr (PK == 4) {
+            return (typename RawPiece<PK>::type)__builtin_amdgcn_raw_buffer_load_b64(rs, voff, row * kRowBytes, 2);
+        } else {
+            return (typename RawPiece<PK>::type)__builtin_amdgcn_raw_buffer_load_b32(rs, voff, row * kRowBytes, 2);
+        }
+    };
 #endif
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         const typename RawPiece<PK>::type raw = v[k & (kWin - 1)];
 #ifndef MH_ROW_GLOBAL
-        if constexpr (PK == 0) {
-            if (k < kRows - kWin)
-                v[k & (kWin - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, voff, (k + kWin) * 1024, 2);
-            else if (HAS_NEXT)
-                v[k & (kWin - 1)] = __builtin_amdgcn_raw_buffer_load_b128(rs_nxt, voff, (k + kWin - kRows) * 1024, 2);
-        } else
-#endif
+        if (k < kRows - kWin)
+            v[k & (kWin - 1)] = row_load(rs_cur, k + kWin);
+        else if (HAS_NEXT)
+            v[k & (kWin - 1)] = row_load(rs_nxt, k + kWin - kRows);
+#else
         if (k < kRows - kWin)
             v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
         else if (HAS_NEXT)
             v[k & (kWin - 1)] = load_row<PK>(nxt + ((uint32_t)(k + kWin - kRows) * kLanes + lane) * piece_bytes<PK>());
+#endif
         if constexpr (PK != 0) {
             encode_row_packed<LC, PK, ABL>(raw, lut2, acc, nb, sp, st, cap);
             continue;
