@@ -231,6 +231,29 @@ def test_production_library_has_no_debug_surface():
     assert "os.environ" not in open(os.path.join(ROOT, "hardware-efficient-mua-compression_amd", "_lib.py")).read()
 
 
+def test_shipped_code_object_has_no_buffer_store_with_a_scalar_register_offset(tmp_path):
+    """gfx950 + hipcc 7.2: `buffer_store_dwordx4 v[a:b], v, s[rsrc], sN offen` (row offset in a scalar REGISTER) gets no
+    wait state before a VALU write of v[a:b] and then stores the new value in lanes 12..15 of every 16 (DESIGN.md
+    section 4; it showed as wrong symbols in row 14 of a decoded chunk).  The decoders therefore put the row offset
+    into the vector offset: every buffer store of the shipped code object must have the literal 0 there."""
+    import shutil
+    import subprocess
+    llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("no ROCm LLVM tools here")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.co")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, _lib.SO], check=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--input=" + fat, "--output=" + co,
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True)
+    asm = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    stores = [ln.split("//")[0].strip() for ln in asm.splitlines() if "buffer_store_" in ln]
+    assert stores, "the wave-task decoders of S <= 6 store through a buffer resource"
+    bad = [ln for ln in stores if not re.search(r"s\[\d+:\d+\], 0( |$)", ln)]
+    assert not bad, bad[:5]
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
 def test_sclv_directory_reader_executes_nothing(tmp_path):
     """load_directory reads reference-shaped Stored_SCLVs_S_<S>.pkl files with a pickle DISASSEMBLER:
     a file whose unpickling would run code is read (or rejected) without running it."""
