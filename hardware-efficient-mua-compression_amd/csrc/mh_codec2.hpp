@@ -567,7 +567,7 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     uint64_t acc = 0;
     uint32_t nb = 0, sp = 0;
     uint32_t *st = stage_lane_base(buf, cap, lane);
-#ifndef MH_ROW_GLOBAL  // (A/B builds: -DMH_ROW_GLOBAL = global loads for the rows, as before)
+    // (A/B builds: -DMH_ROW_GLOBAL = global loads for every encoder's rows, as before)
     // The rows of a chunk through a buffer resource on the chunk's first byte (wave-uniform: four scalar
     // registers) -- the row is an immediate / scalar offset and the lane's 16 bytes one vector register, where a
     // global load needs a 64-bit vector address per row (two VALU adds); and the cache policy is an operand of the
@@ -588,21 +588,28 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
             return (typename RawPiece<PK>::type)__builtin_amdgcn_raw_buffer_load_b32(rs, voff, row * kRowBytes, 2);
         }
     };
-#endif
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
         const typename RawPiece<PK>::type raw = v[k & (kWin - 1)];
+        // (NOT the byte-input encoder of S <= 3: in the headline's alternation -- encode, decode, encode, ... -- the
+        // decode that FOLLOWS that encoder runs 4 % slower when every row was read nt through the buffer form
+        // (2.03 instead of 1.94-1.99 ms, tools/bench_with_lib.py; the encoder itself gains nothing at S = 3))
+        constexpr bool kRowsByBuffer =
 #ifndef MH_ROW_GLOBAL
-        if (k < kRows - kWin)
-            v[k & (kWin - 1)] = row_load(rs_cur, k + kWin);
-        else if (HAS_NEXT)
-            v[k & (kWin - 1)] = row_load(rs_nxt, k + kWin - kRows);
+            !(PK == 0 && LC == 0);
 #else
+            false;
+#endif
+        if constexpr (kRowsByBuffer) {
+            if (k < kRows - kWin)
+                v[k & (kWin - 1)] = row_load(rs_cur, k + kWin);
+            else if (HAS_NEXT)
+                v[k & (kWin - 1)] = row_load(rs_nxt, k + kWin - kRows);
+        } else
         if (k < kRows - kWin)
             v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
         else if (HAS_NEXT)
             v[k & (kWin - 1)] = load_row<PK>(nxt + ((uint32_t)(k + kWin - kRows) * kLanes + lane) * piece_bytes<PK>());
-#endif
         if constexpr (PK != 0) {
             encode_row_packed<LC, PK, ABL>(raw, lut2, acc, nb, sp, st, cap);
             continue;
@@ -1027,8 +1034,11 @@ struct ChunkHdr {
 };
 
 // hw32: word (lane & 31) of the chunk (a full chunk is longer than 32 words)
-// DPP: the prefix sum of the 64 sub-stream lengths as a DPP ladder (mh_device.hpp) -- the decoders whose VALU has room
-// (all but the plain pair-table ones, S = 4..6) take it: S = 3 decode -0.7 %, S = 8 -1.4 % on 1024 ch x 1e7 bins.
+// DPP: the prefix sum of the 64 sub-stream lengths as a DPP ladder (mh_device.hpp): the wave-task decoders (2400 x 72 000
+// S = 3 decode 43.3 -> 41.2 us) and the hybrid long-channel ones (S = 8 -1.5..3 % on 1024 ch x 1e7 bins).  The long-channel
+// S <= 6 decoders keep the ds_bpermute form: with DPP the S = 3 decoder's best runs improve (1.92 ms) but it turns
+// bimodal -- 1.93 or 2.0-2.05 ms from one process to the next on the same box, where the bpermute form holds
+// 1.94-1.95 ms in every run (tools/bench_with_lib.py, profiles/r03_dpp_reductions.txt (11)).
 template <bool DPP = false>
 __device__ __forceinline__ ChunkHdr scan_header(uint32_t hw32, int lane)
 {
@@ -1375,7 +1385,7 @@ __device__ __forceinline__ void decode_segment(const DecArgs &d, uint64_t pos, u
                                                const uint32_t *tab, uint32_t tbase, uint32_t maskW, const uint8_t *tab1,
                                                uint32_t mask1, uint32_t *stage, int lane)
 {
-    constexpr bool kHdrDpp = !(K == 2 && !HY);  // see scan_header
+    constexpr bool kHdrDpp = WT || HY;  // see scan_header
     constexpr int kSt = WT && K != 1 ? 1 : 0;  // see decode_staged_chunk
     constexpr uint32_t kCap = NR * 64;         // words of payload (+3 read-ahead) a staged chunk may have
     constexpr int NV = (NR + 3) / 4;           // 16-byte vectors per lane that cover kCap words
