@@ -466,7 +466,9 @@ def main(argv=None):
     del inputs, best, dat
     torch.cuda.empty_cache()
     plan.encode(cs.data, out=enc)
-    out, place_dec = plan.alloc_output_probed(enc, cs.data, tries=max(1, a.placement_tries - 1))
+    # (five output candidates by default: the decoder's two levels are 1.94 / 2.0-2.1 ms, and a run now and then finds
+    # no fast one among three)
+    out, place_dec = plan.alloc_output_probed(enc, cs.data, tries=1 if a.placement_tries <= 1 else a.placement_tries + 1)
     out.zero_()
     samples = plan.window_samples
 
