@@ -450,13 +450,14 @@ def main(argv=None):
     cs = synth.generate(C, T, seed=a.seed, first_channel=rank * C)
     plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, a.mode, muahuff.WIN_AFTER_CAL, tab, seg_chunks=a.seg_chunks)
     # Buffers of the timed region: chosen by placement (see --placement-tries).  The encoder's level goes with the pages of
-    # the INPUT as much as with those of the payload, so up to three copies of the input are tried, two payload buffers
-    # each; then the output buffer for the decoder.  Every candidate's time goes into the line.
+    # the INPUT as much as with those of the payload, so up to four copies of the input are tried, four payload buffers
+    # each (about one pair in four is on the fast level: six pairs, as tried before, left one run in five without one);
+    # then the output buffer for the decoder.  Every candidate's time goes into the line.
     from muahuff.container import ChannelSet
-    inputs = [cs.data] + [cs.data.clone() for _ in range(min(2, a.placement_tries - 1))]
+    inputs = [cs.data] + [cs.data.clone() for _ in range(min(3, a.placement_tries - 1))]
     place_enc, best = [], None
     for dat in inputs:
-        e_, ms_ = plan.alloc_encoded_probed(dat, tries=min(2, a.placement_tries))
+        e_, ms_ = plan.alloc_encoded_probed(dat, tries=min(4, a.placement_tries))
         place_enc.append(ms_)
         if best is None or min(ms_) < best[0]:
             best = (min(ms_), dat, e_)
