@@ -210,6 +210,53 @@ def per_S_sweep(cs, out, h, mode, seg_chunks, reps=5, tries=3):
     return rows
 
 
+def choose_buffers(plan, data, tries):
+    """Input copy, payload and output buffer of the timed region.  The part runs the same kernel at one of two levels
+    (encode 1.97 / 2.1 ms, decode 1.94 / 2.0-2.1 ms) depending on which physical pages hold the buffers it reads and
+    writes, about one (input, payload) pair in four being on the fast one -- and what the decoder
+    gets depends on the payload it reads as well as on the output it writes.  So: up to 4 input copies x 4 payload buffers
+    timed with the encoder alone; the three best pairs x 4 output buffers timed as the headline runs them, encode and
+    decode alternating; the best triple is kept.  Setup, outside the timed region; every number goes into the line.
+    -> (data, Encoded, out, report)"""
+    from muahuff.codec import _median_ms
+    if tries <= 1:
+        return data, plan.alloc_encoded(), torch.empty_like(data), {"what": "first allocations (--placement-tries 1)"}
+    inputs = [data] + [data.clone() for _ in range(min(3, tries - 1))]
+    table, pairs = [], []
+    for i, dat in enumerate(inputs):
+        row = []
+        for _ in range(min(4, tries)):
+            e = plan.alloc_encoded()
+            ms = _median_ms(lambda: plan.encode(dat, out=e), 4)
+            row.append(ms)
+            pairs.append((ms, i, e))
+        table.append(row)
+    pairs.sort(key=lambda t: t[0])
+    top = pairs[:3]
+    del pairs, e
+    torch.cuda.empty_cache()
+    outs = [torch.empty_like(data) for _ in range(min(4, tries))]
+    joint, best = [], None
+    for _, i, e in top:
+        row = []
+        for o in outs:
+            def step():
+                plan.encode(inputs[i], out=e)
+                plan.decode(e, o)
+            ms = _median_ms(step, 3)
+            row.append(ms)
+            if best is None or ms < best[0]:
+                best = (ms, i, e, o)
+        joint.append(row)
+    report = {"what": "input copy, payload and output buffer of the timed region chosen among candidates alive at the same "
+                      "time: every (input copy, payload) pair timed with 4 encodes (ms per pair), then the three best "
+                      "pairs x every output candidate timed as 3 x (encode, decode) (ms per pair and output); setup, untimed",
+              "encode_ms_per_input_and_payload_candidate": table,
+              "encode_plus_decode_ms_per_top_pair_and_output_candidate": joint,
+              "chosen_encode_plus_decode_ms": best[0]}
+    return inputs[best[1]], best[2], best[3], report
+
+
 def small_shape(S, h, mode, seg_chunks, reps=20):
     """The reference's real shape: 50 ms bins give 2e4-7e4 samples per channel
     (Data/get_all_binned_data.py:16; training set ~2400 channels, get_BR_with_approx_sort.py:24,89-90).
@@ -449,27 +496,13 @@ def main(argv=None):
     tab = sclv.table(S)
     cs = synth.generate(C, T, seed=a.seed, first_channel=rank * C)
     plan = codec.Plan(cs.ch_off, cs.ch_len, S, h, a.mode, muahuff.WIN_AFTER_CAL, tab, seg_chunks=a.seg_chunks)
-    # Buffers of the timed region: chosen by placement (see --placement-tries).  The encoder's level goes with the pages of
-    # the INPUT as much as with those of the payload, so up to four copies of the input are tried, four payload buffers
-    # each (about one pair in four is on the fast level: six pairs, as tried before, left one run in five without one);
-    # then the output buffer for the decoder.  Every candidate's time goes into the line.
+    # Buffers of the timed region: chosen by placement (see --placement-tries, choose_buffers).
     from muahuff.container import ChannelSet
-    inputs = [cs.data] + [cs.data.clone() for _ in range(min(3, a.placement_tries - 1))]
-    place_enc, best = [], None
-    for dat in inputs:
-        e_, ms_ = plan.alloc_encoded_probed(dat, tries=min(4, a.placement_tries))
-        place_enc.append(ms_)
-        if best is None or min(ms_) < best[0]:
-            best = (min(ms_), dat, e_)
-        del e_
-    enc = best[2]
-    cs = ChannelSet(best[1], cs.ch_off, cs.ch_len)
-    del inputs, best, dat
+    data_, enc, out, placement = choose_buffers(plan, cs.data, a.placement_tries)
+    cs = ChannelSet(data_, cs.ch_off, cs.ch_len)
+    del data_
     torch.cuda.empty_cache()
     plan.encode(cs.data, out=enc)
-    # (five output candidates by default: the decoder's two levels are 1.94 / 2.0-2.1 ms, and a run now and then finds
-    # no fast one among three)
-    out, place_dec = plan.alloc_output_probed(enc, cs.data, tries=1 if a.placement_tries <= 1 else a.placement_tries + 1)
     out.zero_()
     samples = plan.window_samples
 
@@ -678,9 +711,7 @@ def main(argv=None):
                            "measure_GBps": meas_samples / meas_ms / 1e6,
                            "measure_window": "[c, c+T/2) reference rule, bits/sample %.4f" % ref_bits_per_sample},
             "roofline": roof,
-            "placement": {"what": "input copy, payload and output buffer of the timed region chosen among candidates alive at "
-                                  "the same time by the median of 4 launches of the real op (setup, untimed); ms per candidate",
-                          "encode_ms_per_input_and_payload_candidate": place_enc, "decode_ms_per_output_candidate": place_dec},
+            "placement": placement,
             "device": info["name"] + " " + info["arch"],
         }
         if dist is not None:
