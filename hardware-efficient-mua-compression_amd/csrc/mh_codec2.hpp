@@ -594,9 +594,10 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
     // registers) -- the row is an immediate / scalar offset and the lane's 16 bytes one vector register, where a
     // global load needs a 64-bit vector address per row (two VALU adds); and the cache policy is an operand of the
     // instruction (aux = 2: nt), not metadata an IR pass may drop (it did, for seven of a chunk's sixteen rows).
-    // 1024 ch x 1e7 bins encode S = 5 / 8 -1.5 %, S = 3 -1 %; 2400 x 72 000 S = 10 -3 % (profiles/r03_dpp_reductions.txt).
-    // (96 ch x 3.6e6 bins in a loop over the SAME 345 MB reads 7 % slower: fewer of its rows now stay in the Infinity
-    // Cache between iterations -- a property of re-reading one small input, not of a recording that is read once.)
+    // 1024 ch x 1e7 bins encode S = 5 / 8 -1.5 %; time-major 1024 x 1e7 block 4.04 -> 3.97 ms; 2400 x 72 000 S = 10 -3 %
+    // (profiles/r03_dpp_reductions.txt).  Used by every encoder but the byte-input one of S <= 3: see kRowsByBuffer.
+    // (A loop over the SAME few hundred MB reads slower this way -- 96 ch x 3.6e6 bins: +2..7 % -- because fewer of its
+    // rows stay in the Infinity Cache between iterations: a property of re-reading one small input.)
     const auto rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(cur), 0, 0x7FFFFFFF, 0x00020000);
     const auto rs_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(nxt), 0, 0x7FFFFFFF, 0x00020000);
     const int voff = lane * (int)piece_bytes<PK>();
@@ -627,11 +628,12 @@ __device__ __forceinline__ void encode_full_chunk(typename RawPiece<PK>::type (&
                 v[k & (kWin - 1)] = row_load(rs_cur, k + kWin);
             else if (HAS_NEXT)
                 v[k & (kWin - 1)] = row_load(rs_nxt, k + kWin - kRows);
-        } else
-        if (k < kRows - kWin)
-            v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
-        else if (HAS_NEXT)
-            v[k & (kWin - 1)] = load_row<PK>(nxt + ((uint32_t)(k + kWin - kRows) * kLanes + lane) * piece_bytes<PK>());
+        } else {
+            if (k < kRows - kWin)
+                v[k & (kWin - 1)] = load_row<PK>(cur + ((uint32_t)(k + kWin) * kLanes + lane) * piece_bytes<PK>());
+            else if (HAS_NEXT)
+                v[k & (kWin - 1)] = load_row<PK>(nxt + ((uint32_t)(k + kWin - kRows) * kLanes + lane) * piece_bytes<PK>());
+        }
         if constexpr (PK != 0) {
             encode_row_packed<LC, PK, ABL>(raw, lut2, acc, nb, sp, st, cap);
             continue;
