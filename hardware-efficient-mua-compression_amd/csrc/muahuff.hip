@@ -1046,6 +1046,7 @@ int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t b
     uint32_t tpw = 4;
 #ifdef MH_TUNING
     if (const char *e = getenv("MH_LAYOUT_TPW")) tpw = (uint32_t)atoi(e);
+    if (bits == 2 && (tpw < 1 || tpw > (uint32_t)mh::kP2Tpw)) tpw = (uint32_t)mh::kP2Tpw;  // (k_deinterleave_p2 holds <= 4 tiles in LDS)
 #endif
     uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
     const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
@@ -1055,7 +1056,7 @@ int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t b
         hipLaunchKernelGGL(mh::k_deinterleave2<4>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
                            out, out_off, layout_ablation(), chunk_stride);
     else
-        hipLaunchKernelGGL(mh::k_deinterleave2<2>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+        hipLaunchKernelGGL(mh::k_deinterleave_p2, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
                            out, out_off, layout_ablation(), chunk_stride);
     MH_HIP(hipGetLastError());
     return MH_OK;
