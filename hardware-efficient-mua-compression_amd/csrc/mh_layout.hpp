@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
     }
 }
 
-// k_deinterleave_p2: time-major bytes -> 2-bit packed pieces (what k_deinterleave2<2> produced, byte for byte), with
+// k_deinterleave_p<2>: time-major bytes -> 2-bit packed pieces (what k_deinterleave2<2> produced, byte for byte), with
 // the PACKING DONE BEFORE THE TURN.  A piece is 16 consecutive time steps of one channel, 2 bits each, little-endian:
 // its byte r holds steps 4r .. 4r+3.  In the time-major matrix those four steps are the same byte column of four
 // consecutive rows, so `V0 | V1 << 2 | V2 << 4 | V3 << 6` of four rows' 16-byte vectors IS byte r of the pieces of 16
@@ -465,23 +465,35 @@ __global__ __launch_bounds__(256) void k_deinterleave2(const uint8_t *__restrict
 // Same grid, tiles, output addressing (plain and chunk-blocked) and zero padding as k_deinterleave2.
 // LDS rows are 32 dwords (128 channels of one packed row); 4 more are skipped after every 16 rows, so that the 16 time
 // quarters x 4 channel groups a wave reads at once sit in 64 different banks.
-constexpr int kP2Tpw = 4;                                    // tiles of kTr2T rows per LDS tile (a workgroup's visit)
-constexpr int kP2Rows = kP2Tpw * kTr2T / 4;                  // packed rows in LDS
-constexpr int kP2Dw = kP2Rows * 32 + (kP2Rows / 16) * 4;     // dwords of the LDS tile
+// (4-bit pieces -- S = 5..16 -- the same way: two rows per packed byte, `V0 | V1 << 4`, so a visit is 512 time steps;
+// its item is 32 steps = two 8-byte pieces per channel, which the SAME four transposes produce: piece p = dwords 2p, 2p+1.)
+template <int PK>
+struct P2 {
+    static constexpr int kRowsPerByte = 8 / PK;                        // time steps per packed row: 4 (2-bit), 2 (4-bit)
+    static constexpr int kTpw = PK == 2 ? 4 : 2;                       // tiles of kTr2T rows per LDS tile (a workgroup's visit)
+    static constexpr int kRows = kTpw * kTr2T / kRowsPerByte;          // packed rows in LDS: 256
+    static constexpr int kDw = kRows * 32 + (kRows / 16) * 4;          // dwords of the LDS tile
+    static constexpr int kItemSteps = 16 * kRowsPerByte;               // time steps of a work item: 64 / 32
+    static constexpr int kGroups = kTr2T / kRowsPerByte / 32;          // packed rows per thread and tile: 2 / 4
+};
+constexpr int kP2Tpw = P2<2>::kTpw;
 __device__ __forceinline__ uint32_t p2_row_dw(uint32_t rg) { return rg * 32u + (rg >> 4) * 4u; }
 
-__global__ __launch_bounds__(256) void k_deinterleave_p2(const uint8_t *__restrict__ in, uint64_t T, uint32_t C, uint32_t tpw,
-                                                         uint8_t *__restrict__ out, const uint64_t *out_off,
-                                                         uint32_t abl = 0, uint64_t blk_stride = 0)
+template <int PK>
+__global__ __launch_bounds__(256) void k_deinterleave_p(const uint8_t *__restrict__ in, uint64_t T, uint32_t C, uint32_t tpw,
+                                                        uint8_t *__restrict__ out, const uint64_t *out_off,
+                                                        uint32_t abl = 0, uint64_t blk_stride = 0, uint32_t cached_stores = 0)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[kP2Dw];
+    typedef P2<PK> G;
+    constexpr int RP = G::kRowsPerByte, NG = G::kGroups;
+    __shared__ __attribute__((aligned(16))) uint32_t tile[G::kDw];
     const uint32_t nstrip = (C + kTr2C - 1) / kTr2C;
     const uint32_t c0 = (blockIdx.x % nstrip) * kTr2C;
     const uint32_t cw = C - c0 < (uint32_t)kTr2C ? C - c0 : (uint32_t)kTr2C;
     const uint64_t ntiles = (T + kTr2T - 1) / kTr2T;
     const uint64_t gx = gridDim.x / nstrip;
-    tpw = tpw < (uint32_t)kP2Tpw ? tpw : (uint32_t)kP2Tpw;  // (the host passes 4; the tuning knob may pass less)
-    // turn: two items per thread, item = (4 channels cg, 64 time steps tq of the visit); lanes = tq fastest
+    tpw = tpw < (uint32_t)G::kTpw ? tpw : (uint32_t)G::kTpw;  // (the host passes kTpw; the tuning knob may pass less)
+    // turn: two items per thread, item = (4 channels cg, 16 packed rows tq of the visit); lanes = tq fastest
     const uint32_t tq = threadIdx.x & 15u;
     uint64_t obase[2][4];
 #pragma unroll
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const uint8_t *__restri
             const uint32_t c = (((threadIdx.x >> 4) + 16u * (uint32_t)u) << 2) + (uint32_t)k;
             obase[u][k] = c < cw ? out_off[c0 + c] : 0;
         }
-    // loads: thread = (16-byte column chunk q, packed row rgl of a tile); two packed rows per thread and tile
+    // loads: thread = (16-byte column chunk q, packed row rgl of a group); NG packed rows per thread and tile
     const uint32_t q = (threadIdx.x & 7u) * 16u, rgl = threadIdx.x >> 3;
     u32x4 V[8];  // the tile in flight: always the NEXT one to be packed, also across visits (its loads run under the turn)
     const uint64_t first = (uint64_t)(blockIdx.x / nstrip) * tpw;
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const uint8_t *__restri
             const uint32_t th = T - t0 < (uint64_t)kTr2T ? (uint32_t)(T - t0) : (uint32_t)kTr2T;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t row = ((uint32_t)(j >> 2) * 32u + rgl) * 4u + (uint32_t)(j & 3);
+                const uint32_t row = ((uint32_t)(j / RP) * 32u + rgl) * (uint32_t)RP + (uint32_t)(j % RP);
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (row < th) {
                     const uint8_t *src = in + (t0 + row) * C + c0 + q;
@@ -521,21 +533,26 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const uint8_t *__restri
         if (tile0 == first) fetch(tile0);
         __syncthreads();  // the previous visit is fully turned
         for (uint64_t tl = tile0; tl < tend; ++tl) {
-            const uint32_t rg0 = (uint32_t)(tl - tile0) * (kTr2T / 4);  // first packed row of this tile in LDS
+            const uint32_t rg0 = (uint32_t)(tl - tile0) * (kTr2T / RP);  // first packed row of this tile in LDS
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                u32x4 a = V[4 * g], b = V[4 * g + 1], c = V[4 * g + 2], e = V[4 * g + 3];
-                const u32x4 any = a | b | c | e;
-                if ((any.x | any.y | any.z | any.w) & 0xFCFCFCFCu) {  // rare: a count above the field's range
+            for (int g = 0; g < NG; ++g) {
+                constexpr uint32_t lim = (1u << PK) - 1u, hi = 0x01010101u * (0xFFu & ~lim);
+                u32x4 r[RP];
+                u32x4 any = {0u, 0u, 0u, 0u};
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        a[w] = clip_bytes(a[w], 3u);
-                        b[w] = clip_bytes(b[w], 3u);
-                        c[w] = clip_bytes(c[w], 3u);
-                        e[w] = clip_bytes(e[w], 3u);
-                    }
+                for (int i = 0; i < RP; ++i) {
+                    r[i] = V[RP * g + i];
+                    any |= r[i];
                 }
-                const u32x4 pv = a | (b << 2) | (c << 4) | (e << 6);
+                if ((any.x | any.y | any.z | any.w) & hi) {  // rare: a count above the field's range
+#pragma unroll
+                    for (int i = 0; i < RP; ++i)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) r[i][w] = clip_bytes(r[i][w], lim);
+                }
+                u32x4 pv = r[0];
+#pragma unroll
+                for (int i = 1; i < RP; ++i) pv |= r[i] << (uint32_t)(PK * i);
                 *reinterpret_cast<u32x4 *>(tile + p2_row_dw(rg0 + (uint32_t)g * 32u + rgl) + (threadIdx.x & 7u) * 4u) = pv;
             }
             if (tl + 1 < tend)
@@ -549,13 +566,13 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const uint8_t *__restri
         // next tile's loads as well)
         for (int u = 0; u < 2; ++u) {
             const uint32_t cg = (threadIdx.x >> 4) + 16u * (uint32_t)u;
-            if (cg * 4 >= cw || tq * 64 >= thv) continue;
+            if (cg * 4 >= cw || tq * G::kItemSteps >= thv) continue;
             uint32_t d[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) d[i] = tile[p2_row_dw(tq * 16u + (uint32_t)i) + cg];
             u32x4 pk[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {  // 16 time steps: byte k of d[4m .. 4m+3] -> piece m of channel k
+            for (int m = 0; m < 4; ++m) {  // byte k of d[4m .. 4m+3] -> dword m of channel k's 16 output bytes
                 const uint32_t a = d[4 * m], b = d[4 * m + 1], c = d[4 * m + 2], e = d[4 * m + 3];
                 const uint32_t t0_ = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
                 const uint32_t t1_ = __builtin_amdgcn_perm(e, c, 0x05010400u);  // c0 e0 c1 e1
@@ -570,11 +587,15 @@ __global__ __launch_bounds__(256) void k_deinterleave_p2(const uint8_t *__restri
             for (int k = 0; k < 4; ++k) {
                 const uint32_t ch = cg * 4 + k;
                 if (ch >= cw) break;
-                const uint64_t piece = (t0v >> 4) + (uint64_t)tq * 4;  // first of the item's four pieces
-                uint8_t *dst = out + obase[u][k] + (blk_stride ? (piece >> 10) * blk_stride + (piece & 1023u) * 4 : piece * 4);
+                constexpr uint32_t kPieceBytes = PK == 4 ? 8 : 4, kItemPieces = 16 / kPieceBytes;
+                const uint64_t piece = (t0v >> 4) + (uint64_t)tq * kItemPieces;  // first of the item's pieces
+                uint8_t *dst = out + obase[u][k] +
+                               (blk_stride ? (piece >> 10) * blk_stride + (piece & 1023u) * kPieceBytes : piece * kPieceBytes);
                 if (abl == 1) {
                     if ((pk[k].x ^ pk[k].y) == 0x12345678u && pk[k].z == 77u) dst[0] = 1;
-                } else if (abl == 4) {  // (A/B: plain stores)
+                } else if (abl == 4 || cached_stores) {
+                    // plain: an intermediate that fits the Infinity Cache is re-read from there by the encoder
+                    // (cached_stores, set by the host for blocks up to 192 MiB of pieces); also the A/B knob
                     *reinterpret_cast<u32x4_u *>(dst) = pk[k];
                 } else {
                     // non-temporal: a wave instruction writes whole lines here (16 lanes x 16 bytes per channel), nothing

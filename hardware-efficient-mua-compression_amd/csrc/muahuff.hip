@@ -1043,21 +1043,27 @@ int mh_deinterleave_packed(const uint8_t *in, uint64_t T, uint32_t C, uint32_t b
     if (chunk_stride && (chunk_stride % 16 || chunk_stride < (uint64_t)MH_CHUNK * bits / 8))
         return fail(MH_ERR_ARG, "mh_deinterleave_packed: chunk_stride=%llu", (unsigned long long)chunk_stride);
     if (T == 0) return MH_OK;
-    uint32_t tpw = 4;
+    const uint32_t tpw_max = bits == 2 ? (uint32_t)mh::P2<2>::kTpw : (uint32_t)mh::P2<4>::kTpw;  // tiles of a visit held in LDS
+    uint32_t tpw = tpw_max;
 #ifdef MH_TUNING
     if (const char *e = getenv("MH_LAYOUT_TPW")) tpw = (uint32_t)atoi(e);
-    if (bits == 2 && (tpw < 1 || tpw > (uint32_t)mh::kP2Tpw)) tpw = (uint32_t)mh::kP2Tpw;  // (k_deinterleave_p2 holds <= 4 tiles in LDS)
+    if (tpw < 1 || tpw > tpw_max) tpw = tpw_max;
 #endif
     uint64_t bx = ((T + mh::kTr2T - 1) / mh::kTr2T + tpw - 1) / tpw;
     const uint32_t by = (C + mh::kTr2C - 1) / mh::kTr2C;
     if (bx > 0x7FFFFFFFull / by) bx = 0x7FFFFFFFull / by;  // one grid dimension: strip fastest
     if (by > 65535) return fail(MH_ERR_ARG, "mh_deinterleave_packed: C=%u too large", C);
+    // pieces that fit the Infinity Cache (256 MiB) stay cacheable for the encoder that reads them next
+    uint32_t cached = (double)T * C * bits / 8.0 <= 192.0 * 1048576.0 ? 1u : 0u;
+#ifdef MH_TUNING
+    if (const char *e = getenv("MH_LAYOUT_CACHED")) cached = (uint32_t)atoi(e);
+#endif
     if (bits == 4)
-        hipLaunchKernelGGL(mh::k_deinterleave2<4>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
-                           out, out_off, layout_ablation(), chunk_stride);
+        hipLaunchKernelGGL(mh::k_deinterleave_p<4>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                           out, out_off, layout_ablation(), chunk_stride, cached);
     else
-        hipLaunchKernelGGL(mh::k_deinterleave_p2, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
-                           out, out_off, layout_ablation(), chunk_stride);
+        hipLaunchKernelGGL(mh::k_deinterleave_p<2>, dim3((unsigned)(bx * by)), dim3(256), 0, (hipStream_t)stream, in, T, C, tpw,
+                           out, out_off, layout_ablation(), chunk_stride, cached);
     MH_HIP(hipGetLastError());
     return MH_OK;
 }
